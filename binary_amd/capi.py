@@ -1,0 +1,82 @@
+"""ctypes binding of the C ABI in include/bivx.h (libbivx.so, hand-written HIP for gfx950).
+
+There is no fallback of any kind: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from ._build import LIB_PATH
+
+BIVX_NO_HIT = 0xFFFFFFFF
+ABI_VERSION = 0x00010000
+
+EXPORTS = (
+    "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_destroy", "bivx_device", "bivx_append",
+    "bivx_append_dev", "bivx_clear", "bivx_build", "bivx_is_built", "bivx_size", "bivx_num_chroms",
+    "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_workspace_bytes", "bivx_count_dev",
+    "bivx_fill_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
+)
+
+
+class BivxError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"libbivx error {code}: {text}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_intervals", C.c_uint64), ("n_chroms", C.c_uint32), ("n_segments", C.c_uint32),
+                ("n_cells", C.c_uint64), ("index_bytes", C.c_uint64), ("staging_bytes", C.c_uint64),
+                ("build_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads binary_amd/libbivx.so; raises if it is not there (build it with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                          "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32p, u64p = C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p
+    L.bivx_abi_version.restype = C.c_uint32
+    L.bivx_last_error.restype = C.c_char_p
+    L.bivx_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.bivx_destroy.argtypes = [vp]
+    L.bivx_destroy.restype = None
+    L.bivx_device.argtypes = [vp]
+    L.bivx_append.argtypes = [vp, u32p, u32p, u32p, sz]
+    L.bivx_append_dev.argtypes = [vp, u32p, u32p, u32p, sz, vp]
+    L.bivx_clear.argtypes = [vp]
+    L.bivx_build.argtypes = [vp]
+    L.bivx_is_built.argtypes = [vp]
+    L.bivx_size.argtypes = [vp]
+    L.bivx_size.restype = sz
+    L.bivx_num_chroms.argtypes = [vp]
+    L.bivx_num_chroms.restype = C.c_uint32
+    L.bivx_get_intervals.argtypes = [vp, u32p, sz, u32p, u32p, u32p]
+    L.bivx_count.argtypes = [vp, u32p, u32p, u32p, sz, u64p]
+    L.bivx_fill.argtypes = [vp, u32p, u32p, u32p, sz, u64p, u32p, C.c_int]
+    L.bivx_count_workspace_bytes.argtypes = [sz]
+    L.bivx_count_workspace_bytes.restype = sz
+    L.bivx_count_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, vp, sz, vp]
+    L.bivx_fill_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, u32p, vp]
+    L.bivx_sort_hits_dev.argtypes = [vp, u64p, u32p, sz, vp]
+    L.bivx_any.argtypes = [vp, u32p, u32p, u32p, sz, u32p]
+    L.bivx_any_dev.argtypes = [vp, u32p, u32p, u32p, sz, u32p, vp]
+    L.bivx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    if L.bivx_abi_version() >> 16 != ABI_VERSION >> 16:
+        raise ImportError("libbivx.so ABI major version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise BivxError(rc, load().bivx_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,651 @@
+// capi.hip — the C ABI of libbivx.so (include/bivx.h) and the host-side build logic.
+//
+// Host code is plain C++ over the HIP runtime: it owns device memory, sequences kernels on a stream and
+// makes the one data-dependent decision of the build (length classes per chromosome). No CPU fallback:
+// every entry point needs a working gfx950 device.
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace bivx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace bivx
+
+using namespace bivx;
+
+struct bivx_index {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // append-order copy (what RbTree::insert_node received, in order)
+  uint32_t *d_chrom = nullptr, *d_low = nullptr, *d_high = nullptr;
+  size_t n = 0, cap = 0;
+  // built index
+  bool built = false;
+  uint2 *d_se = nullptr;
+  uint32_t *d_id = nullptr;
+  uint32_t *d_table = nullptr;
+  SegDesc *d_seg = nullptr;
+  uint32_t *d_chrom_seg = nullptr;
+  uint32_t nchrom = 0, nseg = 0;
+  uint64_t nentries = 0;
+  size_t built_n = 0;
+  double build_ms = 0.0;
+};
+
+namespace {
+
+constexpr double kSearchCost = 16.0;  // cost of one extra segment search, in scanned-candidate units
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+#define BIVX_GUARD(idx)                                               \
+  DeviceGuard bivx_guard_((idx)->device);                             \
+  if (!bivx_guard_.ok) {                                              \
+    set_error("hipSetDevice(%d) failed", (idx)->device);              \
+    return BIVX_E_HIP;                                                \
+  }
+
+// frees everything allocated through it when it goes out of scope (build temporaries)
+struct TempPool {
+  std::vector<void *> ptrs;
+  ~TempPool() {
+    for (void *p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  int alloc(T **out, size_t count) {
+    void *p = nullptr;
+    BIVX_HIP(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+    ptrs.push_back(p);
+    *out = static_cast<T *>(p);
+    return 0;
+  }
+  void release(void *p) {  // ownership moves to the index
+    for (auto &q : ptrs)
+      if (q == p) q = nullptr;
+  }
+};
+
+void free_built(bivx_index *idx) {
+  (void)hipFree(idx->d_se);
+  (void)hipFree(idx->d_id);
+  (void)hipFree(idx->d_table);
+  (void)hipFree(idx->d_seg);
+  (void)hipFree(idx->d_chrom_seg);
+  idx->d_se = nullptr;
+  idx->d_id = nullptr;
+  idx->d_table = nullptr;
+  idx->d_seg = nullptr;
+  idx->d_chrom_seg = nullptr;
+  idx->nchrom = idx->nseg = 0;
+  idx->nentries = 0;
+  idx->built = false;
+}
+
+int ensure_capacity(bivx_index *idx, size_t need) {
+  if (need <= idx->cap) return 0;
+  if (need >= 0xFFFFFFFFull) {
+    set_error("too many intervals: %zu (ids are uint32)", need);
+    return BIVX_E_RANGE;
+  }
+  size_t nc = idx->cap ? idx->cap * 2 : 1024;
+  if (nc < need) nc = need;
+  if (nc > 0xFFFFFFFEull) nc = 0xFFFFFFFEull;
+  uint32_t *c = nullptr, *l = nullptr, *h = nullptr;
+  BIVX_HIP(hipMalloc((void **)&c, nc * sizeof(uint32_t)));
+  BIVX_HIP(hipMalloc((void **)&l, nc * sizeof(uint32_t)));
+  BIVX_HIP(hipMalloc((void **)&h, nc * sizeof(uint32_t)));
+  if (idx->n) {
+    BIVX_HIP(hipMemcpyAsync(c, idx->d_chrom, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
+    BIVX_HIP(hipMemcpyAsync(l, idx->d_low, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
+    BIVX_HIP(hipMemcpyAsync(h, idx->d_high, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
+    BIVX_HIP(hipStreamSynchronize(idx->stream));
+  }
+  (void)hipFree(idx->d_chrom);
+  (void)hipFree(idx->d_low);
+  (void)hipFree(idx->d_high);
+  idx->d_chrom = c;
+  idx->d_low = l;
+  idx->d_high = h;
+  idx->cap = nc;
+  return 0;
+}
+
+int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high, size_t n,
+                hipMemcpyKind kind, hipStream_t s) {
+  if (!idx || (n && (!low || !high))) {
+    set_error("bivx_append: null argument");
+    return BIVX_E_INVALID;
+  }
+  if (n == 0) return 0;
+  BIVX_GUARD(idx);
+  BIVX_TRY(ensure_capacity(idx, idx->n + n));
+  if (chrom)
+    BIVX_HIP(hipMemcpyAsync(idx->d_chrom + idx->n, chrom, n * 4, kind, s));
+  else
+    BIVX_HIP(hipMemsetAsync(idx->d_chrom + idx->n, 0, n * 4, s));
+  BIVX_HIP(hipMemcpyAsync(idx->d_low + idx->n, low, n * 4, kind, s));
+  BIVX_HIP(hipMemcpyAsync(idx->d_high + idx->n, high, n * 4, kind, s));
+  if (kind == hipMemcpyHostToDevice) BIVX_HIP(hipStreamSynchronize(s));  // caller may reuse its buffers
+  idx->n += n;
+  idx->built = false;
+  return 0;
+}
+
+struct ClassPlan {
+  std::vector<uint32_t> bin2seg;       // nchrom * kLenBins, 0xFFFFFFFF for empty bins
+  std::vector<SegDesc> segs;           // grouped by chromosome, classes by ascending length
+  std::vector<uint32_t> chrom_seg;     // nchrom + 1
+  uint64_t nentries = 0;
+  uint32_t max_low = 0;
+};
+
+// Chooses, per chromosome, how to cut the 33 length bins into classes. A class is searched with two
+// directory lookups (cost kSearchCost) and scans about density * max_len candidates that cannot be hits;
+// a tiny dynamic programme over the non-empty bins minimises the sum. Uniform short intervals end up in
+// one class; a few chromosome-scale intervals get a class of their own instead of widening every window.
+int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &plan) {
+  plan.bin2seg.assign((size_t)nchrom * kLenBins, 0xFFFFFFFFu);
+  plan.chrom_seg.assign(nchrom + 1, 0);
+  plan.segs.clear();
+  uint64_t begin = 0, table_off = 0;
+  for (uint32_t c = 0; c < nchrom; ++c) {
+    plan.chrom_seg[c] = (uint32_t)plan.segs.size();
+    int bins[kLenBins], m = 0;
+    for (int b = 0; b < kLenBins; ++b)
+      if (st[(size_t)c * kLenBins + b].count) bins[m++] = b;
+    if (m == 0) continue;
+    double best[kLenBins + 1];
+    int cut[kLenBins + 1];
+    best[0] = 0.0;
+    for (int j = 1; j <= m; ++j) {
+      best[j] = 1e300;
+      uint64_t cnt = 0;
+      uint32_t mn = 0xFFFFFFFFu, mx = 0, ml = 0;
+      for (int i = j; i >= 1; --i) {  // class = bins[i-1 .. j-1]
+        const BinStats &s = st[(size_t)c * kLenBins + bins[i - 1]];
+        cnt += s.count;
+        mn = s.min_low < mn ? s.min_low : mn;
+        mx = s.max_low > mx ? s.max_low : mx;
+        ml = s.max_len > ml ? s.max_len : ml;
+        const double span = (double)(mx - mn) + 1.0;
+        double waste = (double)cnt * ((double)ml + 1.0) / span;
+        if (waste > (double)cnt) waste = (double)cnt;
+        const double cost = best[i - 1] + kSearchCost + waste;
+        if (cost < best[j]) {
+          best[j] = cost;
+          cut[j] = i - 1;
+        }
+      }
+    }
+    // walk the cuts back, then emit classes in ascending length order
+    int starts[kLenBins], ns = 0;
+    for (int j = m; j > 0; j = cut[j]) starts[ns++] = cut[j];
+    for (int k = ns - 1; k >= 0; --k) {
+      const int i0 = starts[k], i1 = (k == 0) ? m : starts[k - 1];
+      SegDesc d{};
+      uint64_t cnt = 0;
+      uint32_t mn = 0xFFFFFFFFu, mx = 0, ml = 0;
+      for (int i = i0; i < i1; ++i) {
+        const BinStats &s = st[(size_t)c * kLenBins + bins[i]];
+        cnt += s.count;
+        mn = s.min_low < mn ? s.min_low : mn;
+        mx = s.max_low > mx ? s.max_low : mx;
+        ml = s.max_len > ml ? s.max_len : ml;
+        plan.bin2seg[(size_t)c * kLenBins + bins[i]] = (uint32_t)plan.segs.size();
+      }
+      d.begin = (uint32_t)begin;
+      d.end = (uint32_t)(begin + cnt);
+      d.base = mn;
+      d.last = mx;
+      d.maxlen = ml;
+      const uint64_t span = (uint64_t)mx - mn;
+      const uint64_t target = cnt / 2 > 1 ? cnt / 2 : 1;
+      uint32_t sh = 0;
+      while (sh < 31 && (span >> sh) + 1 > target) ++sh;
+      d.shift = sh;
+      d.ncell = (uint32_t)((span >> sh) + 1);
+      if (table_off + d.ncell + 1 > 0xFFFFFFFFull) {
+        set_error("bucket directory too large");
+        return BIVX_E_RANGE;
+      }
+      d.table_off = (uint32_t)table_off;
+      table_off += (uint64_t)d.ncell + 1;
+      begin += cnt;
+      if (mx > plan.max_low) plan.max_low = mx;
+      plan.segs.push_back(d);
+    }
+  }
+  plan.chrom_seg[nchrom] = (uint32_t)plan.segs.size();
+  plan.nentries = table_off;
+  return 0;
+}
+
+int bits_for(uint32_t maxval) {
+  int b = 0;
+  while (maxval) {
+    ++b;
+    maxval >>= 1;
+  }
+  return b;
+}
+
+IndexView view_of(const bivx_index *idx) {
+  IndexView v;
+  v.se = idx->d_se;
+  v.id = idx->d_id;
+  v.table = idx->d_table;
+  v.seg = idx->d_seg;
+  v.chrom_seg = idx->d_chrom_seg;
+  v.nchrom = idx->nchrom;
+  v.nseg = idx->nseg;
+  return v;
+}
+
+int check_query_args(const bivx_index *idx, const void *qlow, const void *qhigh, size_t q, const char *who) {
+  if (!idx || (q && (!qlow || !qhigh))) {
+    set_error("%s: null argument", who);
+    return BIVX_E_INVALID;
+  }
+  if (!idx->built) {
+    set_error("%s: index not built (call bivx_build after the last append)", who);
+    return BIVX_E_STATE;
+  }
+  return 0;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+uint32_t bivx_abi_version(void) { return BIVX_ABI_VERSION; }
+const char *bivx_last_error(void) { return g_err; }
+
+int bivx_create(bivx_index **out, int device) {
+  if (!out) {
+    set_error("bivx_create: null out");
+    return BIVX_E_INVALID;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("bivx_create: no HIP device (this library has no CPU fallback)");
+    return BIVX_E_HIP;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("bivx_create: device %d out of range [0, %d)", device, ndev);
+    return BIVX_E_INVALID;
+  }
+  bivx_index *idx = new (std::nothrow) bivx_index();
+  if (!idx) {
+    set_error("bivx_create: out of host memory");
+    return BIVX_E_NOMEM;
+  }
+  idx->device = device;
+  DeviceGuard g(device);
+  if (!g.ok || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("bivx_create: cannot create a stream on device %d", device);
+    delete idx;
+    return BIVX_E_HIP;
+  }
+  *out = idx;
+  return 0;
+}
+
+void bivx_destroy(bivx_index *idx) {
+  if (!idx) return;
+  DeviceGuard g(idx->device);
+  if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+  free_built(idx);
+  (void)hipFree(idx->d_chrom);
+  (void)hipFree(idx->d_low);
+  (void)hipFree(idx->d_high);
+  if (idx->stream) (void)hipStreamDestroy(idx->stream);
+  delete idx;
+}
+
+int bivx_device(const bivx_index *idx) { return idx ? idx->device : -1; }
+
+int bivx_append(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high, size_t n) {
+  return append_impl(idx, chrom, low, high, n, hipMemcpyHostToDevice, idx ? idx->stream : nullptr);
+}
+
+int bivx_append_dev(bivx_index *idx, const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
+                    size_t n, void *stream) {
+  return append_impl(idx, d_chrom, d_low, d_high, n, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+}
+
+int bivx_clear(bivx_index *idx) {
+  if (!idx) {
+    set_error("bivx_clear: null index");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  BIVX_HIP(hipStreamSynchronize(idx->stream));
+  free_built(idx);
+  idx->n = 0;
+  return 0;
+}
+
+int bivx_build(bivx_index *idx) {
+  if (!idx) {
+    set_error("bivx_build: null index");
+    return BIVX_E_INVALID;
+  }
+  if (idx->built && idx->built_n == idx->n) return 0;
+  BIVX_GUARD(idx);
+  const auto t0 = std::chrono::steady_clock::now();
+  hipStream_t s = idx->stream;
+  // appends made with bivx_append_dev on a caller stream must be complete before we read them
+  BIVX_HIP(hipDeviceSynchronize());
+  free_built(idx);
+  const size_t n = idx->n;
+  TempPool tmp;
+
+  // 1. number of chromosome ids
+  uint32_t *d_scalar = nullptr;
+  BIVX_TRY(tmp.alloc(&d_scalar, 1));
+  BIVX_TRY(launch_max_u32(idx->d_chrom, n, d_scalar, s));
+  uint32_t max_chrom = 0;
+  BIVX_HIP(hipMemcpyAsync(&max_chrom, d_scalar, 4, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  if (n && max_chrom >= BIVX_MAX_CHROMS) {
+    set_error("chromosome id %u exceeds BIVX_MAX_CHROMS", max_chrom);
+    return BIVX_E_RANGE;
+  }
+  const uint32_t nchrom = n ? max_chrom + 1 : 0;
+
+  // 2. per (chromosome, length bin) statistics -> host
+  std::vector<BinStats> st((size_t)nchrom * kLenBins);
+  ClassPlan plan;
+  if (n) {
+    BinStats *d_stats = nullptr;
+    BIVX_TRY(tmp.alloc(&d_stats, st.size()));
+    BIVX_TRY(launch_bin_stats(idx->d_chrom, idx->d_low, idx->d_high, n, nchrom, d_stats, s));
+    BIVX_HIP(hipMemcpyAsync(st.data(), d_stats, st.size() * sizeof(BinStats), hipMemcpyDeviceToHost, s));
+    BIVX_HIP(hipStreamSynchronize(s));
+  }
+  // 3. length classes, segment descriptors
+  BIVX_TRY(plan_classes(st, nchrom, plan));
+  const uint32_t nseg = (uint32_t)plan.segs.size();
+
+  BIVX_HIP(hipMalloc((void **)&idx->d_chrom_seg, (size_t)(nchrom + 1) * 4));
+  BIVX_HIP(hipMemcpyAsync(idx->d_chrom_seg, plan.chrom_seg.data(), (size_t)(nchrom + 1) * 4, hipMemcpyHostToDevice, s));
+  BIVX_HIP(hipMalloc((void **)&idx->d_seg, (size_t)(nseg ? nseg : 1) * sizeof(SegDesc)));
+  if (nseg)
+    BIVX_HIP(hipMemcpyAsync(idx->d_seg, plan.segs.data(), (size_t)nseg * sizeof(SegDesc), hipMemcpyHostToDevice, s));
+
+  if (n) {
+    // 4. sort keys
+    uint32_t *d_bin2seg = nullptr, *d_segkey = nullptr, *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr;
+    void *d_rscr = nullptr;
+    BIVX_TRY(tmp.alloc(&d_bin2seg, plan.bin2seg.size()));
+    BIVX_TRY(tmp.alloc(&d_segkey, n));
+    BIVX_TRY(tmp.alloc(&kA, n));
+    BIVX_TRY(tmp.alloc(&kB, n));
+    BIVX_TRY(tmp.alloc(&vA, n));
+    BIVX_TRY(tmp.alloc(&vB, n));
+    {
+      uint8_t *p = nullptr;
+      BIVX_TRY(tmp.alloc(&p, radix_scratch_bytes(n)));
+      d_rscr = p;
+    }
+    BIVX_HIP(hipMemcpyAsync(d_bin2seg, plan.bin2seg.data(), plan.bin2seg.size() * 4, hipMemcpyHostToDevice, s));
+    BIVX_TRY(launch_make_segkeys(idx->d_chrom, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey, vA, s));
+    BIVX_HIP(hipMemcpyAsync(kA, idx->d_low, n * 4, hipMemcpyDeviceToDevice, s));
+    // 5. stable sort by low, then by segment (LSD): final order (segment, low, id)
+    BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), d_rscr, s));
+    if (nseg > 1) {
+      BIVX_TRY(launch_gather_u32(d_segkey, vA, kA, n, s));
+      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), d_rscr, s));
+    }
+    // 6. sorted (low, high) pairs; ids
+    BIVX_HIP(hipMalloc((void **)&idx->d_se, n * sizeof(uint2)));
+    BIVX_TRY(launch_gather_se(idx->d_low, idx->d_high, vA, idx->d_se, n, s));
+    idx->d_id = vA;
+    tmp.release(vA);
+    // 7. bucket directory
+    BIVX_HIP(hipMalloc((void **)&idx->d_table, (size_t)plan.nentries * 4));
+    BIVX_TRY(launch_build_table(idx->d_se, idx->d_seg, nseg, idx->d_table, plan.nentries, s));
+  }
+  BIVX_HIP(hipStreamSynchronize(s));
+  idx->nchrom = nchrom;
+  idx->nseg = nseg;
+  idx->nentries = plan.nentries;
+  idx->built = true;
+  idx->built_n = n;
+  idx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int bivx_is_built(const bivx_index *idx) { return idx && idx->built && idx->built_n == idx->n; }
+size_t bivx_size(const bivx_index *idx) { return idx ? idx->n : 0; }
+uint32_t bivx_num_chroms(const bivx_index *idx) { return idx ? idx->nchrom : 0; }
+
+int bivx_get_intervals(const bivx_index *idx, const uint32_t *ids, size_t n, uint32_t *chrom_out, uint32_t *low_out,
+                       uint32_t *high_out) {
+  if (!idx || (n && !ids)) {
+    set_error("bivx_get_intervals: null argument");
+    return BIVX_E_INVALID;
+  }
+  if (n == 0) return 0;
+  BIVX_GUARD(idx);
+  hipStream_t s = idx->stream;
+  TempPool tmp;
+  uint32_t *d_ids = nullptr, *d_c = nullptr, *d_l = nullptr, *d_h = nullptr;
+  BIVX_TRY(tmp.alloc(&d_ids, n));
+  if (chrom_out) BIVX_TRY(tmp.alloc(&d_c, n));
+  if (low_out) BIVX_TRY(tmp.alloc(&d_l, n));
+  if (high_out) BIVX_TRY(tmp.alloc(&d_h, n));
+  BIVX_HIP(hipMemcpyAsync(d_ids, ids, n * 4, hipMemcpyHostToDevice, s));
+  BIVX_TRY(launch_gather_intervals(idx->d_chrom, idx->d_low, idx->d_high, d_ids, n, idx->n, d_c, d_l, d_h, s));
+  if (chrom_out) BIVX_HIP(hipMemcpyAsync(chrom_out, d_c, n * 4, hipMemcpyDeviceToHost, s));
+  if (low_out) BIVX_HIP(hipMemcpyAsync(low_out, d_l, n * 4, hipMemcpyDeviceToHost, s));
+  if (high_out) BIVX_HIP(hipMemcpyAsync(high_out, d_h, n * 4, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+size_t bivx_count_workspace_bytes(size_t q) { return align_up((q ? q : 1) * 4, 256) + scan_scratch_bytes(q) + 256; }
+
+int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                   size_t q, uint64_t *d_offsets, void *d_workspace, size_t workspace_bytes, void *stream) {
+  BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_count_dev"));
+  if (!d_offsets) {
+    set_error("bivx_count_dev: null d_offsets");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t need = bivx_count_workspace_bytes(q);
+  void *ws = d_workspace;
+  bool own = false;
+  if (!ws) {
+    BIVX_HIP(hipMallocAsync(&ws, need, s));
+    own = true;
+  } else if (workspace_bytes < need) {
+    set_error("bivx_count_dev: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return BIVX_E_INVALID;
+  }
+  uint32_t *d_counts = static_cast<uint32_t *>(ws);
+  void *scan_scr = static_cast<uint8_t *>(ws) + align_up((q ? q : 1) * 4, 256);
+  int rc = launch_count(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_counts, s);
+  if (rc == 0) rc = exclusive_scan_u32_u64(d_counts, d_offsets, q, scan_scr, s);
+  if (own) (void)hipFreeAsync(ws, s);
+  return rc;
+}
+
+int bivx_fill_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                  size_t q, const uint64_t *d_offsets, uint32_t *d_hit_ids, void *stream) {
+  BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_fill_dev"));
+  if (q && !d_offsets) {
+    set_error("bivx_fill_dev: null d_offsets");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  return launch_fill(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, static_cast<hipStream_t>(stream));
+}
+
+int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q, void *stream) {
+  if (!idx || (q && !d_offsets)) {
+    set_error("bivx_sort_hits_dev: null argument");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  return launch_sort_hits(d_offsets, d_hit_ids, q, static_cast<hipStream_t>(stream));
+}
+
+int bivx_any_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                 size_t q, uint32_t *d_first_id, void *stream) {
+  BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_any_dev"));
+  if (q && !d_first_id) {
+    set_error("bivx_any_dev: null output");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  return launch_any(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_first_id, static_cast<hipStream_t>(stream));
+}
+
+// ---- host-pointer convenience entry points -----------------------------------------------------------------
+
+namespace {
+struct DevQueries {
+  uint32_t *c = nullptr, *lo = nullptr, *hi = nullptr;
+};
+int upload_queries(TempPool &tmp, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
+                   hipStream_t s, DevQueries &d) {
+  BIVX_TRY(tmp.alloc(&d.lo, q));
+  BIVX_TRY(tmp.alloc(&d.hi, q));
+  BIVX_HIP(hipMemcpyAsync(d.lo, qlow, q * 4, hipMemcpyHostToDevice, s));
+  BIVX_HIP(hipMemcpyAsync(d.hi, qhigh, q * 4, hipMemcpyHostToDevice, s));
+  if (qchrom) {
+    BIVX_TRY(tmp.alloc(&d.c, q));
+    BIVX_HIP(hipMemcpyAsync(d.c, qchrom, q * 4, hipMemcpyHostToDevice, s));
+  }
+  return 0;
+}
+}  // namespace
+
+int bivx_count(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
+               uint64_t *offsets_out) {
+  BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_count"));
+  if (!offsets_out) {
+    set_error("bivx_count: null offsets_out");
+    return BIVX_E_INVALID;
+  }
+  if (q == 0) {
+    offsets_out[0] = 0;
+    return 0;
+  }
+  BIVX_GUARD(idx);
+  hipStream_t s = idx->stream;
+  TempPool tmp;
+  DevQueries d;
+  BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
+  uint64_t *d_off = nullptr;
+  uint8_t *d_ws = nullptr;
+  const size_t wsb = bivx_count_workspace_bytes(q);
+  BIVX_TRY(tmp.alloc(&d_off, q + 1));
+  BIVX_TRY(tmp.alloc(&d_ws, wsb));
+  BIVX_TRY(bivx_count_dev(idx, d.c, d.lo, d.hi, q, d_off, d_ws, wsb, s));
+  BIVX_HIP(hipMemcpyAsync(offsets_out, d_off, (q + 1) * 8, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
+              const uint64_t *offsets, uint32_t *hit_ids_out, int sort_by_id) {
+  BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_fill"));
+  if (q == 0) return 0;
+  if (!offsets) {
+    set_error("bivx_fill: null offsets");
+    return BIVX_E_INVALID;
+  }
+  const uint64_t total = offsets[q];
+  if (total && !hit_ids_out) {
+    set_error("bivx_fill: null hit_ids_out");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  hipStream_t s = idx->stream;
+  TempPool tmp;
+  DevQueries d;
+  BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
+  uint64_t *d_off = nullptr;
+  uint32_t *d_hits = nullptr;
+  BIVX_TRY(tmp.alloc(&d_off, q + 1));
+  BIVX_TRY(tmp.alloc(&d_hits, (size_t)total));
+  BIVX_HIP(hipMemcpyAsync(d_off, offsets, (q + 1) * 8, hipMemcpyHostToDevice, s));
+  BIVX_TRY(bivx_fill_dev(idx, d.c, d.lo, d.hi, q, d_off, d_hits, s));
+  if (sort_by_id) BIVX_TRY(bivx_sort_hits_dev(idx, d_off, d_hits, q, s));
+  if (total) BIVX_HIP(hipMemcpyAsync(hit_ids_out, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
+             uint32_t *first_id_out) {
+  BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_any"));
+  if (q == 0) return 0;
+  if (!first_id_out) {
+    set_error("bivx_any: null output");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  hipStream_t s = idx->stream;
+  TempPool tmp;
+  DevQueries d;
+  BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
+  uint32_t *d_first = nullptr;
+  BIVX_TRY(tmp.alloc(&d_first, q));
+  BIVX_TRY(bivx_any_dev(idx, d.c, d.lo, d.hi, q, d_first, s));
+  BIVX_HIP(hipMemcpyAsync(first_id_out, d_first, q * 4, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int bivx_get_stats(const bivx_index *idx, bivx_stats *out) {
+  if (!idx || !out) {
+    set_error("bivx_get_stats: null argument");
+    return BIVX_E_INVALID;
+  }
+  memset(out, 0, sizeof(*out));
+  out->n_intervals = idx->n;
+  out->n_chroms = idx->nchrom;
+  out->n_segments = idx->nseg;
+  out->n_cells = idx->nentries;
+  out->staging_bytes = (uint64_t)idx->cap * 12;
+  if (idx->built)
+    out->index_bytes = (uint64_t)idx->built_n * 12 + idx->nentries * 4 + (uint64_t)idx->nseg * sizeof(SegDesc) +
+                       ((uint64_t)idx->nchrom + 1) * 4;
+  out->build_ms = idx->build_ms;
+  return 0;
+}
+
+}  // extern "C"

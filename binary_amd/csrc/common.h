@@ -1,0 +1,99 @@
+// common.h — shared declarations of libbivx (gfx950 only; no CUDA path, no CPU fallback).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/bivx.h"
+
+namespace bivx {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define BIVX_HIP(call)                                                                              \
+  do {                                                                                              \
+    hipError_t bivx_e_ = (call);                                                                    \
+    if (bivx_e_ != hipSuccess) {                                                                    \
+      ::bivx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(bivx_e_), __FILE__,       \
+                        __LINE__);                                                                  \
+      return BIVX_E_HIP;                                                                            \
+    }                                                                                               \
+  } while (0)
+
+#define BIVX_TRY(call)              \
+  do {                              \
+    int bivx_rc_ = (call);          \
+    if (bivx_rc_ != 0) return bivx_rc_; \
+  } while (0)
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kLenBins = 33;       // bin 0: len == 0 (incl. low > high); bin b: len in [2^(b-1), 2^b)
+
+// One (chromosome, length class) segment of the sorted arrays plus its bucket directory.
+struct SegDesc {        // 32 B, read as two dwordx4
+  uint32_t begin, end;  // element range [begin, end) in se[] / id[]
+  uint32_t base, last;  // min / max `low` in the segment
+  uint32_t shift;       // directory cell of coordinate x: (x - base) >> shift
+  uint32_t table_off;   // first directory entry; the segment owns ncell + 1 entries
+  uint32_t maxlen;      // max over the segment of (high >= low ? high - low : 0)
+  uint32_t ncell;
+};
+static_assert(sizeof(SegDesc) == 32, "SegDesc layout");
+
+// Device view of a built index, passed to kernels by value.
+struct IndexView {
+  const uint2 *se;            // (low, high) sorted by (segment, low, id)
+  const uint32_t *id;         // append-order id of each sorted slot
+  const uint32_t *table;      // bucket directories, all segments back to back
+  const SegDesc *seg;         // nseg descriptors, grouped by chromosome
+  const uint32_t *chrom_seg;  // nchrom + 1: segments of chromosome c are [chrom_seg[c], chrom_seg[c+1])
+  uint32_t nchrom;
+  uint32_t nseg;
+};
+
+// per (chromosome, length bin) statistics gathered before the sort
+struct BinStats {
+  uint32_t count;
+  uint32_t min_low;
+  uint32_t max_low;
+  uint32_t max_len;
+};
+
+// ---- scan.hip ---------------------------------------------------------------------------------------
+// out[0..n] = exclusive prefix sums of in[0..n), out[n] = total. scratch: scan_scratch_bytes(n).
+size_t scan_scratch_bytes(size_t n);
+int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s);
+int exclusive_scan_u32_u32(const uint32_t *d_in, uint32_t *d_out, size_t n, void *d_scratch, hipStream_t s);
+
+// ---- build.hip --------------------------------------------------------------------------------------
+int launch_bin_stats(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n,
+                     uint32_t nchrom, BinStats *d_stats, hipStream_t s);
+int launch_max_u32(const uint32_t *d_in, size_t n, uint32_t *d_out, hipStream_t s);
+int launch_make_segkeys(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n,
+                        const uint32_t *d_bin2seg, uint32_t *d_segkey, uint32_t *d_ids, hipStream_t s);
+// stable LSD radix sort of (key, val) pairs on key bits [0, nbits); result ends in (*keys, *vals)
+// (the pointers are swapped with the alt buffers as passes ping-pong). scratch: radix_scratch_bytes(n).
+size_t radix_scratch_bytes(size_t n);
+int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint32_t **vals_alt, size_t n,
+                     int nbits, void *d_scratch, hipStream_t s);
+int launch_gather_u32(const uint32_t *d_src, const uint32_t *d_idx, uint32_t *d_dst, size_t n, hipStream_t s);
+int launch_gather_se(const uint32_t *d_low, const uint32_t *d_high, const uint32_t *d_idx, uint2 *d_se,
+                     size_t n, hipStream_t s);
+int launch_build_table(const uint2 *d_se, const SegDesc *d_seg, uint32_t nseg, uint32_t *d_table,
+                       uint64_t ncells_total, hipStream_t s);
+int launch_gather_intervals(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
+                            const uint32_t *d_ids, size_t n, size_t n_intervals, uint32_t *d_c, uint32_t *d_l,
+                            uint32_t *d_h, hipStream_t s);
+
+// ---- query.hip --------------------------------------------------------------------------------------
+int launch_count(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                 size_t q, uint32_t *d_counts, hipStream_t s);
+int launch_fill(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                size_t q, const uint64_t *d_offsets, uint32_t *d_hits, hipStream_t s);
+int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+               size_t q, uint32_t *d_first, hipStream_t s);
+int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, hipStream_t s);
+
+}  // namespace bivx

@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's IntervalTree interface over the C ABI (include/bivx.h).
+
+The reference API (library/include/binary/algorithm/interval_tree.hpp:140-187, rb_tree.hpp:97-171) is
+per-record: insert_node(...), find_overlaps(interval) -> vector, find_overlap(interval) -> optional,
+size(), empty(). This class keeps those names and meanings but takes whole arrays, because one device
+batch replaces the reference's per-record calls. PyTorch is used only as the owner of device buffers and
+streams; every result comes from the hand-written HIP kernels in libbivx.so. No CPU path exists here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+try:  # torch is plumbing (device memory, streams); the host-pointer API works without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _u32(a) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype == np.int32:
+        a = a.view(np.uint32)
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _tptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check_dev_tensor(t, name, n=None, itemsize=4):
+    if not (torch is not None and isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+        raise TypeError(f"{name}: expected a contiguous device tensor")
+    if t.element_size() != itemsize:
+        raise TypeError(f"{name}: expected {itemsize}-byte elements, got {t.dtype}")
+    if n is not None and t.numel() != n:
+        raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
+
+
+class IntervalIndex:
+    """Batched drop-in for IntervalTree<UIntIntervalNode> (+ a chromosome id per interval/query)."""
+
+    def __init__(self, device: int = 0):
+        self._L = capi.load()
+        h = C.c_void_p()
+        capi.check(self._L.bivx_create(C.byref(h), int(device)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.bivx_destroy(h)
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- build side (RbTree::insert_node, rb_tree.hpp:111-117,145-149) ---------------------------------
+    def insert_node(self, low, high, chrom=None) -> None:
+        """Append intervals [low[i], high[i]] (closed); ids continue in append order."""
+        if torch is not None and isinstance(low, torch.Tensor) and low.is_cuda:
+            n = low.numel()
+            _check_dev_tensor(low, "low")
+            _check_dev_tensor(high, "high", n)
+            if chrom is not None:
+                _check_dev_tensor(chrom, "chrom", n)
+            s = torch.cuda.current_stream(low.device).cuda_stream
+            capi.check(self._L.bivx_append_dev(self._h, _tptr(chrom), _tptr(low), _tptr(high), n, C.c_void_p(s)))
+            torch.cuda.current_stream(low.device).synchronize()  # the copy reads caller memory
+            return
+        low, high = _u32(low).ravel(), _u32(high).ravel()
+        if low.shape != high.shape:
+            raise ValueError("low and high must have the same length")
+        c = None if chrom is None else _u32(chrom).ravel()
+        if c is not None and c.shape != low.shape:
+            raise ValueError("chrom must have the same length as low")
+        capi.check(self._L.bivx_append(self._h, _ptr(c), _ptr(low), _ptr(high), low.size))
+
+    def build(self) -> None:
+        """Makes the appended set searchable (the reference does this incrementally per insert)."""
+        capi.check(self._L.bivx_build(self._h))
+
+    def clear(self) -> None:
+        capi.check(self._L.bivx_clear(self._h))
+
+    def size(self) -> int:  # RbTree::size rb_tree.hpp:173-180
+        return int(self._L.bivx_size(self._h))
+
+    def empty(self) -> bool:  # RbTree::empty rb_tree.hpp:182-184
+        return self.size() == 0
+
+    def num_chroms(self) -> int:
+        return int(self._L.bivx_num_chroms(self._h))
+
+    def stats(self) -> dict:
+        st = capi.Stats()
+        capi.check(self._L.bivx_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def get_intervals(self, ids):
+        ids = _u32(ids).ravel()
+        c, lo, hi = (np.empty(ids.size, np.uint32) for _ in range(3))
+        capi.check(self._L.bivx_get_intervals(self._h, _ptr(ids), ids.size, _ptr(c), _ptr(lo), _ptr(hi)))
+        return c, lo, hi
+
+    def count_workspace_bytes(self, q: int) -> int:
+        return int(self._L.bivx_count_workspace_bytes(int(q)))
+
+    def _ensure_built(self):
+        if not self._L.bivx_is_built(self._h):
+            self.build()
+
+    # ---- query side, host arrays (IntervalTree::find_overlaps interval_tree.hpp:161-168,306-334) -------
+    def find_overlaps(self, qlow, qhigh, qchrom=None, sort_by_id: bool = True):
+        """CSR of all overlaps: (offsets uint64[q+1], hit_ids uint32[H])."""
+        self._ensure_built()
+        qlow, qhigh = _u32(qlow).ravel(), _u32(qhigh).ravel()
+        if qlow.shape != qhigh.shape:
+            raise ValueError("qlow and qhigh must have the same length")
+        qc = None if qchrom is None else _u32(qchrom).ravel()
+        q = qlow.size
+        offsets = np.zeros(q + 1, dtype=np.uint64)
+        capi.check(self._L.bivx_count(self._h, _ptr(qc), _ptr(qlow), _ptr(qhigh), q, _ptr(offsets)))
+        hits = np.empty(int(offsets[-1]), dtype=np.uint32)
+        capi.check(self._L.bivx_fill(self._h, _ptr(qc), _ptr(qlow), _ptr(qhigh), q, _ptr(offsets), _ptr(hits),
+                                     1 if sort_by_id else 0))
+        return offsets, hits
+
+    def find_overlap(self, qlow, qhigh, qchrom=None) -> np.ndarray:
+        """Per query the smallest overlapping id, or capi.BIVX_NO_HIT (find_overlap, interval_tree.hpp:290-304)."""
+        self._ensure_built()
+        qlow, qhigh = _u32(qlow).ravel(), _u32(qhigh).ravel()
+        qc = None if qchrom is None else _u32(qchrom).ravel()
+        first = np.empty(qlow.size, dtype=np.uint32)
+        capi.check(self._L.bivx_any(self._h, _ptr(qc), _ptr(qlow), _ptr(qhigh), qlow.size, _ptr(first)))
+        return first
+
+    # ---- query side, device tensors (no host round trip except the hit total) --------------------------
+    def count_overlaps_device(self, qlow, qhigh, qchrom=None, offsets=None, workspace=None):
+        """offsets int64[q+1] on the device (exclusive prefix of hit counts); asynchronous."""
+        self._ensure_built()
+        q = qlow.numel()
+        _check_dev_tensor(qlow, "qlow")
+        _check_dev_tensor(qhigh, "qhigh", q)
+        if qchrom is not None:
+            _check_dev_tensor(qchrom, "qchrom", q)
+        if offsets is None:
+            offsets = torch.empty(q + 1, dtype=torch.int64, device=qlow.device)
+        _check_dev_tensor(offsets, "offsets", q + 1, 8)
+        need = int(self._L.bivx_count_workspace_bytes(q))
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.uint8, device=qlow.device)
+        _check_dev_tensor(workspace, "workspace", None, 1)
+        s = torch.cuda.current_stream(qlow.device).cuda_stream
+        capi.check(self._L.bivx_count_dev(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q, _tptr(offsets),
+                                          _tptr(workspace), workspace.numel(), C.c_void_p(s)))
+        return offsets
+
+    def fill_overlaps_device(self, qlow, qhigh, offsets, hits, qchrom=None, sort_by_id: bool = False):
+        """Writes hit ids into `hits` (int32/uint32 device tensor with >= offsets[-1] elements); asynchronous."""
+        q = qlow.numel()
+        _check_dev_tensor(offsets, "offsets", q + 1, 8)
+        _check_dev_tensor(hits, "hits")
+        s = C.c_void_p(torch.cuda.current_stream(qlow.device).cuda_stream)
+        capi.check(self._L.bivx_fill_dev(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q, _tptr(offsets),
+                                         _tptr(hits), s))
+        if sort_by_id:
+            capi.check(self._L.bivx_sort_hits_dev(self._h, _tptr(offsets), _tptr(hits), q, s))
+        return hits
+
+    def find_overlaps_device(self, qlow, qhigh, qchrom=None, sort_by_id: bool = False):
+        """(offsets int64[q+1], hits int32[H]) as device tensors. One host sync to size the hit buffer."""
+        offsets = self.count_overlaps_device(qlow, qhigh, qchrom)
+        total = int(offsets[-1].item())
+        hits = torch.empty(max(total, 1), dtype=torch.int32, device=qlow.device)
+        self.fill_overlaps_device(qlow, qhigh, offsets, hits, qchrom, sort_by_id)
+        return offsets, hits[:total]
+
+    def find_overlap_device(self, qlow, qhigh, qchrom=None):
+        self._ensure_built()
+        q = qlow.numel()
+        first = torch.empty(q, dtype=torch.int32, device=qlow.device)
+        s = C.c_void_p(torch.cuda.current_stream(qlow.device).cuda_stream)
+        capi.check(self._L.bivx_any_dev(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q, _tptr(first), s))
+        return first

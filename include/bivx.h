@@ -1,0 +1,141 @@
+/*
+ * bivx.h — C ABI of libbivx.so: the MI355X (gfx950) interval-overlap engine that stands behind
+ * ylab-hi/BINARY's IntervalTree query API (binary::algorithm::tree, library/include/binary/algorithm/).
+ *
+ * The reference has no FFI/plugin boundary of its own: its boundary is the C++20 template API of a
+ * header-only library. This header is the boundary a maintainer binds instead; every entry point cites
+ * the reference interface it replaces (paths relative to the reference root). The C++20 facade in
+ * include/binary/algorithm/interval_tree.hpp is the in-tree caller; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++/torch types; no exceptions cross the ABI
+ *   - return 0 on success, a negative bivx_status otherwise; bivx_last_error() gives the thread-local text
+ *   - interval ids are 0-based APPEND ORDER indices (the reference's insertion order, rb_tree.hpp:111-117)
+ *   - intervals are closed [low, high] over uint32 keys, overlap predicate exactly
+ *     q.low <= high && low <= q.high (BaseInterval::is_overlap, interval_tree.hpp:119-121);
+ *     low > high is accepted and handled exactly like the reference tree handles it
+ *   - chrom ids partition the index: an interval and a query only meet when their chrom ids are equal
+ *     (sv2nl builds one tree per chromosome, standalone/sv2nl/include/mapper.hpp:147-162,199);
+ *     pass NULL chrom arrays for a single tree
+ *   - calls taking `const bivx_index*` are thread-safe against each other; mutating calls are not
+ *   - `_dev` entry points take DEVICE pointers and a hipStream_t (as void*; NULL = default stream) and
+ *     never synchronise; the others take HOST pointers and return when the result is in host memory
+ *   - there is no CPU fallback: without a usable gfx950 device bivx_create fails with BIVX_E_HIP
+ */
+#ifndef BIVX_H_
+#define BIVX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bivx_index bivx_index;
+
+typedef enum bivx_status {
+  BIVX_OK = 0,
+  BIVX_E_INVALID = -1, /* bad argument */
+  BIVX_E_HIP = -2,     /* a HIP runtime call failed (text in bivx_last_error) */
+  BIVX_E_NOMEM = -3,   /* host allocation failed */
+  BIVX_E_STATE = -4,   /* e.g. query before build */
+  BIVX_E_RANGE = -5    /* too many intervals (>= 2^32-1) or chromosome ids (> BIVX_MAX_CHROMS) */
+} bivx_status;
+
+#define BIVX_MAX_CHROMS 65536u
+#define BIVX_NO_HIT 0xFFFFFFFFu
+
+/* ABI version of this header: major << 16 | minor. */
+#define BIVX_ABI_VERSION 0x00010000u
+uint32_t bivx_abi_version(void);
+const char *bivx_last_error(void);
+
+/* ---- lifetime ---------------------------------------------------------------------------------
+ * replaces: IntervalTree<Node>{} construction / destruction (interval_tree.hpp:140, rb_tree.hpp:103,109);
+ * the tree owns its nodes (rb_tree.hpp:169), the handle owns all device memory of the index. */
+int bivx_create(bivx_index **out, int device);
+void bivx_destroy(bivx_index *idx);
+int bivx_device(const bivx_index *idx);
+
+/* ---- build side -------------------------------------------------------------------------------
+ * replaces: RbTree::insert_node(range) rb_tree.hpp:111-117 and insert_node(Args&&...) :145-149 — appends n
+ * intervals; ids continue from bivx_size(). chrom may be NULL (all chrom 0). Host pointers. */
+int bivx_append(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high, size_t n);
+/* same, device pointers, asynchronous on `stream` */
+int bivx_append_dev(bivx_index *idx, const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
+                    size_t n, void *stream);
+/* drops all intervals (keeps the allocation) */
+int bivx_clear(bivx_index *idx);
+
+/* replaces the net effect of IntervalTree::insert_node_impl interval_tree.hpp:230-260 + RbTree::fix_insert
+ * rb_tree.hpp:304-344 + the rotations :206-228: makes the appended set searchable. On the GPU that is a
+ * per-chromosome, per-length-class start-sorted array with a bucket directory. Idempotent;
+ * runs on the index's own stream and returns when the index is ready. */
+int bivx_build(bivx_index *idx);
+int bivx_is_built(const bivx_index *idx);
+
+/* replaces: RbTree::size() rb_tree.hpp:173-180 (number of intervals appended) */
+size_t bivx_size(const bivx_index *idx);
+/* number of chromosome ids in use after build (max id + 1) */
+uint32_t bivx_num_chroms(const bivx_index *idx);
+
+/* reads back appended intervals by id (what the facade needs to materialise interval_type copies,
+ * interval_tree.hpp:316). Host pointers; any output may be NULL. */
+int bivx_get_intervals(const bivx_index *idx, const uint32_t *ids, size_t n, uint32_t *chrom_out,
+                       uint32_t *low_out, uint32_t *high_out);
+
+/* ---- query side: all overlaps ------------------------------------------------------------------
+ * replaces: IntervalTree::find_overlaps interval_tree.hpp:161-168,306-334, batched over q queries.
+ * Result is CSR: offsets[q+1] (exclusive prefix of per-query hit counts, offsets[q] == total hits H)
+ * and hit_ids[H]; query i's hits are hit_ids[offsets[i] .. offsets[i+1]).
+ * Hit order inside one query: deterministic "index order" (ascending (length class, low, id)) straight
+ * out of bivx_fill*, ascending id after bivx_sort_hits*. The reference returns RB-tree pre-order, a
+ * function of insertion history; as a SET the result is identical (tests compare sorted lists).
+ *
+ * Two calls because H is unknown a priori: count -> caller allocates hit_ids[H] -> fill. */
+int bivx_count(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+               size_t q, uint64_t *offsets_out);
+int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+              size_t q, const uint64_t *offsets, uint32_t *hit_ids_out, int sort_by_id);
+
+/* device-resident variants. d_workspace: bivx_count_workspace_bytes(q) bytes of scratch (NULL => the call
+ * allocates and frees stream-ordered scratch itself). */
+size_t bivx_count_workspace_bytes(size_t q);
+int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                   const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, void *d_workspace,
+                   size_t workspace_bytes, void *stream);
+int bivx_fill_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                  const uint32_t *d_qhigh, size_t q, const uint64_t *d_offsets, uint32_t *d_hit_ids,
+                  void *stream);
+/* sorts every query's hit list ascending by id, in place */
+int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q,
+                       void *stream);
+
+/* ---- query side: existence ---------------------------------------------------------------------
+ * replaces: IntervalTree::find_overlap interval_tree.hpp:152-159,290-304 (std::optional<interval_type>).
+ * first_id_out[i] = smallest id among query i's hits, or BIVX_NO_HIT. The reference returns whichever
+ * overlapping node its single root-to-leaf descent meets first (tree-shape dependent, and it misses
+ * hits when q.low == 0 meets a null left child, interval_tree.hpp:297 with get_max(nullptr) == 0);
+ * this entry point is exact on existence and canonical on choice (documented deviation). */
+int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+             size_t q, uint32_t *first_id_out);
+int bivx_any_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                 const uint32_t *d_qhigh, size_t q, uint32_t *d_first_id, void *stream);
+
+/* ---- introspection (bench / DESIGN.md numbers) -------------------------------------------------- */
+typedef struct bivx_stats {
+  uint64_t n_intervals;
+  uint32_t n_chroms;
+  uint32_t n_segments;      /* (chromosome, length class) pairs */
+  uint64_t n_cells;         /* bucket directory entries */
+  uint64_t index_bytes;     /* device bytes of the built index (sorted arrays + directory) */
+  uint64_t staging_bytes;   /* device bytes of the append-order copy */
+  double build_ms;          /* wall time of the last bivx_build */
+} bivx_stats;
+int bivx_get_stats(const bivx_index *idx, bivx_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIVX_H_ */

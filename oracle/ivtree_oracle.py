@@ -186,3 +186,11 @@ def sorted_csr(offsets: np.ndarray, hits: np.ndarray) -> np.ndarray:
     qid = np.repeat(np.arange(offsets.size - 1, dtype=np.int64), np.diff(offsets))
     order = np.lexsort((hits.astype(np.int64), qid))
     return hits.astype(np.int64)[order]
+
+
+def count_overlaps_numpy(low, high, qlow, qhigh) -> np.ndarray:
+    """Per-query hit counts from the predicate alone, for sets where every low <= high and every
+    qlow <= qhigh: #(low <= qhigh) - #(high < qlow). Sort + searchsorted, so it runs at any size."""
+    low, high = np.sort(_u32(low)), np.sort(_u32(high))
+    qlow, qhigh = _u32(qlow), _u32(qhigh)
+    return (np.searchsorted(low, qhigh, side="right") - np.searchsorted(high, qlow, side="left")).astype(np.int64)

@@ -1,0 +1,69 @@
+"""CPU-side checks of the boundary: libbivx.so builds for gfx950, loads, exports every symbol that
+include/bivx.h declares, and refuses to work (loudly) when there is no GPU. No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bivx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bivx_[a-z_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from binary_amd import _build, capi
+    _build.build_lib()
+    return capi.load()
+
+
+def test_header_symbols_all_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libbivx.so does not export {n}"
+    from binary_amd import capi
+    assert sorted(capi.EXPORTS) == names  # the python binding covers the whole header
+
+
+def test_abi_version(lib):
+    assert lib.bivx_abi_version() == 0x00010000
+
+
+def test_code_object_is_gfx950(lib):
+    from binary_amd._build import LIB_PATH
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", LIB_PATH],
+                         capture_output=True, text=True).stdout
+    if not out:
+        pytest.skip("llvm-objdump --offloading unavailable")
+    assert "gfx950" in out and "gfx9" in out
+    assert not re.search(r"gfx(90a|942|1[0-9]{3})", out)
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = lib.bivx_create(C.byref(h), 0)
+    assert rc == -2 and not h.value  # BIVX_E_HIP: there is no CPU fallback
+    assert b"no HIP device" in lib.bivx_last_error() or b"fallback" in lib.bivx_last_error()
+    from binary_amd import IntervalIndex, BivxError
+    with pytest.raises(BivxError):
+        IntervalIndex(0)
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle."""
+    for base in ("binary_amd", "include", "tools"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".c")):
+                    text = open(os.path.join(dp, f), errors="replace").read()
+                    assert "oracle" not in text.lower() or f in (), f"{dp}/{f} mentions the oracle"

@@ -1,0 +1,289 @@
+"""GPU parity: the HIP path (through the C ABI of include/bivx.h) against the CPU oracle and the golden
+vectors. Bit-exact bar: per query the hit SET (ascending ids) equals the reference tree's hit set.
+
+All tests here need a real MI355X (-m gpu). The oracle is only the checker.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+RT, FX = GOLD["reference_tests"], GOLD["fixture10"]
+M32 = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def IntervalIndex():
+    from binary_amd import IntervalIndex as cls
+    return cls
+
+
+def gpu_csr(IntervalIndex, low, high, qlow, qhigh, chrom=None, qchrom=None, sort_by_id=True):
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high, chrom)
+        idx.build()
+        return idx.find_overlaps(qlow, qhigh, qchrom, sort_by_id=sort_by_id)
+
+
+def oracle_csr_sorted(oracle, low, high, qlow, qhigh):
+    t = oracle.OracleTree(low, high)
+    off, hits = t.find_overlaps_batch(qlow, qhigh, nthreads=4)
+    return off, oracle.sorted_csr(off, hits)
+
+
+def assert_same(oracle, low, high, qlow, qhigh, IntervalIndex):
+    off_g, hits_g = gpu_csr(IntervalIndex, low, high, qlow, qhigh)
+    off_o, hits_o = oracle_csr_sorted(oracle, low, high, qlow, qhigh)
+    assert np.array_equal(off_g, off_o)
+    assert np.array_equal(hits_g.astype(np.int64), hits_o)
+
+
+# ---- the reference's own known answers, through the C ABI ----------------------------------------------
+
+def test_reference_fixture10(IntervalIndex, oracle):
+    with IntervalIndex(0) as idx:
+        idx.insert_node(FX["low"], FX["high"])
+        assert idx.size() == RT["fixture10_size"]["value"]
+        q1, q2 = RT["find_overlaps_7_25_count"], RT["find_overlaps_15_25_count"]
+        off, hits = idx.find_overlaps([q1["q"][0], q2["q"][0]], [q1["q"][1], q2["q"][1]])
+        assert np.diff(off.astype(np.int64)).tolist() == [q1["count"], q2["count"]]
+        for k, name in enumerate(("find_overlaps_7_25_preorder", "find_overlaps_15_25_preorder")):
+            got = sorted([FX["low"][i], FX["high"][i]] for i in hits[int(off[k]):int(off[k + 1])])
+            assert got == sorted(GOLD["survey_8c"][name])
+        # find_overlap: existence must match (22,25) -> some hit, (100,111) -> none
+        first = idx.find_overlap([22, 100], [25, 111])
+        assert first[0] != M32 and first[1] == M32
+        # (22,25) overlaps exactly [15,23] and [25,30]; the reference returns [15,23] (id 5), the smaller id
+        assert [FX["low"][first[0]], FX["high"][first[0]]] == RT["find_overlap_22_25"]["hit"]
+
+
+def test_reference_duplicates(IntervalIndex):
+    d = RT["dup4"]
+    off, hits = gpu_csr(IntervalIndex, d["low"], d["high"], [d["q"][0]], [d["q"][1]])
+    assert int(off[1]) == d["count"] and hits.tolist() == [0, 1, 2, 3]
+
+
+def test_reference_seq500(IntervalIndex, oracle):
+    s = RT["seq500"]
+    low = np.arange(s["start"], s["stop"], s["step"], dtype=np.uint32)
+    q = np.arange(0, 1010, 7, dtype=np.uint32)
+    assert_same(oracle, low, low + s["len"], q, q + 5, IntervalIndex)
+
+
+# ---- edge cases ------------------------------------------------------------------------------------------
+
+def test_empty_index_and_empty_batch(IntervalIndex):
+    with IntervalIndex(0) as idx:
+        assert idx.empty()
+        off, hits = idx.find_overlaps([0, 5], [10, M32])
+        assert off.tolist() == [0, 0, 0] and hits.size == 0
+        assert idx.find_overlap([3], [4]).tolist() == [M32]
+        idx.insert_node([1], [2])
+        off, hits = idx.find_overlaps(np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+        assert off.tolist() == [0] and hits.size == 0
+        off, hits = idx.find_overlaps([2, 3], [2, 3])  # one node
+        assert off.tolist() == [0, 1, 1] and hits.tolist() == [0]
+
+
+def test_boundary_touching(IntervalIndex, oracle):
+    low = np.array([10, 20, 20, 30, 31], dtype=np.uint32)
+    high = np.array([20, 20, 25, 30, 40], dtype=np.uint32)
+    qlo = np.array([0, 9, 20, 21, 25, 26, 30, 41, 0], dtype=np.uint32)
+    qhi = np.array([9, 10, 20, 24, 30, 29, 31, 50, M32], dtype=np.uint32)
+    assert_same(oracle, low, high, qlo, qhi, IntervalIndex)
+
+
+def test_u32_extremes(IntervalIndex, oracle):
+    low = np.array([0, 0, M32, M32 - 1, 5, M32 - 1000], dtype=np.uint32)
+    high = np.array([0, M32, M32, M32, 5, M32 - 1], dtype=np.uint32)
+    qlo = np.array([0, M32, 0, 6, 1, M32 - 500], dtype=np.uint32)
+    qhi = np.array([0, M32, M32, M32 - 2, 4, M32 - 400], dtype=np.uint32)
+    assert_same(oracle, low, high, qlo, qhi, IntervalIndex)
+
+
+def test_low_greater_than_high_intervals_and_queries(IntervalIndex, oracle):
+    """TraMapper inserts unvalidated BND records (mapper.cpp:158-170): low > high nodes are legal."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    low = rng.integers(0, 20000, size=n).astype(np.uint32)
+    high = low + rng.integers(0, 400, size=n).astype(np.uint32)
+    swap = rng.random(n) < 0.2
+    low2, high2 = np.where(swap, high, low).astype(np.uint32), np.where(swap, low, high).astype(np.uint32)
+    qlo = rng.integers(0, 20000, size=2000).astype(np.uint32)
+    qhi = qlo + rng.integers(0, 400, size=2000).astype(np.uint32)
+    qswap = rng.random(2000) < 0.1  # and a few inverted queries
+    qlo2, qhi2 = np.where(qswap, qhi, qlo).astype(np.uint32), np.where(qswap, qlo, qhi).astype(np.uint32)
+    assert_same(oracle, low2, high2, qlo2, qhi2, IntervalIndex)
+
+
+@pytest.mark.parametrize("n,q", [(1, 1), (2, 2), (63, 65), (64, 64), (65, 63), (1000, 1000), (100000, 100000)])
+def test_random_sets_vs_oracle(IntervalIndex, oracle, n, q):
+    from binary_amd import synth
+    L = 1 << 20 if n <= 1000 else 248956422 // 10
+    low, high = synth.gen_intervals(n, L, 1000, chrom_index=n % 7)
+    qlo, qhi = synth.gen_range_queries(q, L, 1000, chrom_index=q % 5)
+    assert_same(oracle, low, high, qlo, qhi, IntervalIndex)
+
+
+def test_mixed_lengths_force_length_classes_and_heavy_windows(IntervalIndex, oracle):
+    """A few chromosome-scale intervals among many short ones: several length classes, windows that
+    take the wavefront-cooperative path, hit lists long enough for every tier of the id sort."""
+    rng = np.random.default_rng(9)
+    L = 5_000_000
+    n_short = 60000
+    low = rng.integers(0, L, size=n_short).astype(np.uint32)
+    high = low + rng.integers(0, 200, size=n_short).astype(np.uint32)
+    big_low = rng.integers(0, L // 2, size=40).astype(np.uint32)
+    big_high = big_low + rng.integers(L // 4, L // 2, size=40).astype(np.uint32)
+    mid_low = rng.integers(0, L, size=3000).astype(np.uint32)
+    mid_high = mid_low + rng.integers(5000, 60000, size=3000).astype(np.uint32)
+    low = np.concatenate([low, big_low, mid_low])
+    high = np.concatenate([high, big_high, mid_high])
+    perm = rng.permutation(low.size)
+    low, high = low[perm], high[perm]
+    qlo = rng.integers(0, L, size=3000).astype(np.uint32)
+    qhi = qlo + rng.integers(0, 300, size=3000).astype(np.uint32)
+    # long queries: hundreds to tens of thousands of hits each
+    qlo[:40] = rng.integers(0, L // 2, size=40)
+    qhi[:40] = qlo[:40] + rng.integers(10_000, L // 2, size=40).astype(np.uint32)
+    qlo[40], qhi[40] = 0, M32  # everything
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        assert idx.stats()["n_segments"] >= 2
+        off_g, hits_g = idx.find_overlaps(qlo, qhi)
+        off_n, hits_n = idx.find_overlaps(qlo, qhi, sort_by_id=False)
+        first = idx.find_overlap(qlo, qhi)
+    off_o, hits_o = oracle_csr_sorted(oracle, low, high, qlo, qhi)
+    assert np.array_equal(off_g, off_o)
+    assert np.array_equal(hits_g.astype(np.int64), hits_o)
+    assert int(np.diff(off_o.astype(np.int64)).max()) > 2048
+    # index-order output is the same set
+    assert np.array_equal(off_n, off_o)
+    assert np.array_equal(oracle.sorted_csr(off_n, hits_n.astype(np.int32)), hits_o)
+    # find_overlap: existence exact, choice = smallest id
+    cnt = np.diff(off_o.astype(np.int64))
+    exp_first = np.where(cnt > 0, hits_o[np.minimum(off_o[:-1].astype(np.int64), max(hits_o.size - 1, 0))], M32)
+    assert np.array_equal(first.astype(np.int64), exp_first)
+
+
+def test_chromosomes_partition_the_index(IntervalIndex, oracle):
+    """One tree per chromosome in sv2nl (mapper.hpp:147-162,199): equal chrom ids meet, others never."""
+    rng = np.random.default_rng(21)
+    nchrom, n, q = 7, 20000, 15000
+    chrom = rng.integers(0, nchrom, size=n).astype(np.uint32)
+    chrom[chrom == 3] = 4  # chromosome 3 stays empty
+    low = rng.integers(0, 200000, size=n).astype(np.uint32)
+    high = low + rng.integers(0, 500, size=n).astype(np.uint32)
+    qchrom = rng.integers(0, nchrom + 3, size=q).astype(np.uint32)  # ids 7..9 do not exist in the index
+    qlo = rng.integers(0, 200000, size=q).astype(np.uint32)
+    qhi = qlo + rng.integers(0, 500, size=q).astype(np.uint32)
+    off_g, hits_g = gpu_csr(IntervalIndex, low, high, qlo, qhi, chrom, qchrom)
+    cnt_g = np.diff(off_g.astype(np.int64))
+    for c in range(nchrom + 3):
+        sel_i = np.nonzero(chrom == c)[0]
+        sel_q = np.nonzero(qchrom == c)[0]
+        if sel_i.size == 0:
+            assert cnt_g[sel_q].sum() == 0
+            continue
+        t = oracle.OracleTree(low[sel_i], high[sel_i])
+        off_o, hits_o = t.find_overlaps_batch(qlo[sel_q], qhi[sel_q])
+        assert np.array_equal(cnt_g[sel_q], np.diff(off_o.astype(np.int64)))
+        for k in (0, sel_q.size // 2, sel_q.size - 1):
+            qi = sel_q[k]
+            got = hits_g[int(off_g[qi]):int(off_g[qi + 1])].astype(np.int64)
+            exp = np.sort(sel_i[hits_o[int(off_o[k]):int(off_o[k + 1])]])
+            assert np.array_equal(got, exp)
+        got_all = np.concatenate([hits_g[int(off_g[qi]):int(off_g[qi + 1])] for qi in sel_q]).astype(np.int64)
+        exp_all = sel_i[oracle.sorted_csr(off_o, hits_o)] if hits_o.size else np.zeros(0, np.int64)
+        # oracle.sorted_csr sorts local ids; local order == global order because sel_i is ascending
+        assert np.array_equal(got_all, exp_all)
+
+
+def test_incremental_append_rebuilds(IntervalIndex, oracle):
+    rng = np.random.default_rng(2)
+    low = rng.integers(0, 50000, size=4000).astype(np.uint32)
+    high = low + rng.integers(0, 100, size=4000).astype(np.uint32)
+    qlo = rng.integers(0, 50000, size=1000).astype(np.uint32)
+    qhi = qlo + 50
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low[:1500], high[:1500])
+        o1, h1 = idx.find_overlaps(qlo, qhi)
+        idx.insert_node(low[1500:], high[1500:])  # ids continue
+        o2, h2 = idx.find_overlaps(qlo, qhi)
+        c, lo_back, hi_back = idx.get_intervals(np.array([0, 1499, 1500, 3999], dtype=np.uint32))
+        assert lo_back.tolist() == low[[0, 1499, 1500, 3999]].tolist()
+        assert hi_back.tolist() == high[[0, 1499, 1500, 3999]].tolist()
+    off_a, hits_a = oracle_csr_sorted(oracle, low[:1500], high[:1500], qlo, qhi)
+    off_b, hits_b = oracle_csr_sorted(oracle, low, high, qlo, qhi)
+    assert np.array_equal(o1, off_a) and np.array_equal(h1.astype(np.int64), hits_a)
+    assert np.array_equal(o2, off_b) and np.array_equal(h2.astype(np.int64), hits_b)
+
+
+def test_device_resident_path_matches_host_path(IntervalIndex):
+    import torch
+    from binary_amd import synth
+    low, high = synth.gen_intervals(50000, 10_000_000, 1000)
+    qlo, qhi = synth.gen_range_queries(30000, 10_000_000, 1000)
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(to(low), to(high))  # device append
+        idx.build()
+        off_h, hits_h = idx.find_overlaps(qlo, qhi, sort_by_id=True)
+        off_d, hits_d = idx.find_overlaps_device(to(qlo), to(qhi), sort_by_id=True)
+        first_d = idx.find_overlap_device(to(qlo), to(qhi))
+        first_h = idx.find_overlap(qlo, qhi)
+        torch.cuda.synchronize()
+    assert np.array_equal(off_d.cpu().numpy().astype(np.uint64), off_h)
+    assert np.array_equal(hits_d.cpu().numpy().view(np.uint32), hits_h)
+    assert np.array_equal(first_d.cpu().numpy().view(np.uint32), first_h)
+
+
+# ---- full BASELINE sizes through size-independent properties ------------------------------------------------
+
+def _check_full(IntervalIndex, oracle, data, point):
+    """count == predicate count (sort+searchsorted), every reported pair satisfies the predicate, ids
+    strictly ascending inside a query  =>  the hit set is exactly the reference's."""
+    with IntervalIndex(0) as idx:
+        idx.insert_node(data["low"], data["high"], data["chrom"])
+        idx.build()
+        off, hits = idx.find_overlaps(data["qlow"], data["qhigh"], data["qchrom"], sort_by_id=True)
+    cnt = np.diff(off.astype(np.int64))
+    exp = np.zeros_like(cnt)
+    for c in np.unique(data["qchrom"]):
+        qi = data["qchrom"] == c
+        ii = data["chrom"] == c
+        exp[qi] = oracle.count_overlaps_numpy(data["low"][ii], data["high"][ii], data["qlow"][qi], data["qhigh"][qi])
+    assert np.array_equal(cnt, exp)
+    qid = np.repeat(np.arange(cnt.size), cnt)
+    assert np.all(data["chrom"][hits] == data["qchrom"][qid])
+    assert np.all(data["qlow"][qid] <= data["high"][hits]) and np.all(data["low"][hits] <= data["qhigh"][qid])
+    same_q = qid[1:] == qid[:-1]
+    assert np.all(hits[1:][same_q].astype(np.int64) > hits[:-1][same_q].astype(np.int64))
+    return int(off[-1])
+
+
+def test_config2_full_size_1M_x_1M_point(IntervalIndex, oracle):
+    from binary_amd import synth
+    L = int(synth.HG38_LENGTHS[0])
+    low, high = synth.gen_intervals(1_000_000, L, 1000, 0)
+    qlo, qhi = synth.gen_point_queries(1_000_000, L, 0)
+    z = np.zeros(1_000_000, np.uint32)
+    H = _check_full(IntervalIndex, oracle, dict(chrom=z, low=low, high=high, qchrom=z, qlow=qlo, qhigh=qhi), True)
+    # and against the reference-algorithm oracle itself on the full batch (a few seconds on 4 threads)
+    off_g, hits_g = gpu_csr(IntervalIndex, low, high, qlo, qhi)
+    off_o, hits_o = oracle_csr_sorted(oracle, low, high, qlo, qhi)
+    assert int(off_o[-1]) == H
+    assert np.array_equal(off_g, off_o) and np.array_equal(hits_g.astype(np.int64), hits_o)
+
+
+def test_config3_full_size_24_chroms_10M_x_10M_range(IntervalIndex, oracle):
+    from binary_amd import synth
+    data = synth.gen_genome(10_000_000, 10_000_000, 1000, point_queries=False)
+    H = _check_full(IntervalIndex, oracle, data, False)
+    assert 25_000_000 < H < 40_000_000  # SURVEY §8d expects about 32 M
