@@ -16,7 +16,7 @@ EXPORTS = (
     "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_destroy", "bivx_device", "bivx_append",
     "bivx_append_dev", "bivx_clear", "bivx_build", "bivx_is_built", "bivx_size", "bivx_num_chroms",
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_workspace_bytes", "bivx_count_dev",
-    "bivx_fill_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
+    "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
 )
 
 
@@ -67,6 +67,9 @@ def load() -> C.CDLL:
     L.bivx_count_workspace_bytes.restype = sz
     L.bivx_count_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, vp, sz, vp]
     L.bivx_fill_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, u32p, vp]
+    L.bivx_query_workspace_bytes.argtypes = [sz]
+    L.bivx_query_workspace_bytes.restype = sz
+    L.bivx_query_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, u32p, C.c_uint64, vp, sz, vp]
     L.bivx_sort_hits_dev.argtypes = [vp, u64p, u32p, sz, vp]
     L.bivx_any.argtypes = [vp, u32p, u32p, u32p, sz, u32p]
     L.bivx_any_dev.argtypes = [vp, u32p, u32p, u32p, sz, u32p, vp]

@@ -426,7 +426,10 @@ int bivx_build(bivx_index *idx) {
       BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), d_rscr, s));
     }
     // 6. sorted (low, high) pairs; ids
-    BIVX_HIP(hipMalloc((void **)&idx->d_se, n * sizeof(uint2)));
+    // two spare slots: query lanes read (low, high) pairs two at a time (16 B), so the pair holding the last
+    // slot may reach one slot past the end
+    BIVX_HIP(hipMalloc((void **)&idx->d_se, (n + 2) * sizeof(uint2)));
+    BIVX_HIP(hipMemsetAsync(idx->d_se + n, 0xFF, 2 * sizeof(uint2), s));
     BIVX_TRY(launch_gather_se(idx->d_low, idx->d_high, vA, idx->d_se, n, s));
     idx->d_id = vA;
     tmp.release(vA);
@@ -510,6 +513,25 @@ int bivx_fill_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_
   }
   BIVX_GUARD(idx);
   return launch_fill(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, static_cast<hipStream_t>(stream));
+}
+
+size_t bivx_query_workspace_bytes(size_t q) { return fused_workspace_bytes(q); }
+
+int bivx_query_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                   size_t q, uint64_t *d_offsets, uint32_t *d_hit_ids, uint64_t hit_capacity, void *d_workspace,
+                   size_t workspace_bytes, void *stream) {
+  BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_query_dev"));
+  if (!d_offsets || (hit_capacity && !d_hit_ids) || !d_workspace) {
+    set_error("bivx_query_dev: null argument");
+    return BIVX_E_INVALID;
+  }
+  if (workspace_bytes < fused_workspace_bytes(q)) {
+    set_error("bivx_query_dev: workspace too small (%zu < %zu)", workspace_bytes, fused_workspace_bytes(q));
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  return launch_query_fused(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, hit_capacity,
+                            d_workspace, static_cast<hipStream_t>(stream));
 }
 
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q, void *stream) {

@@ -108,6 +108,15 @@ int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32
 int bivx_fill_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                   const uint32_t *d_qhigh, size_t q, const uint64_t *d_offsets, uint32_t *d_hit_ids,
                   void *stream);
+/* Single pass for callers that already own a hit buffer (steady-state serving): one kernel counts, chains
+ * the prefix across workgroups and fills. d_offsets[q] receives the true total H even when H >
+ * hit_capacity; in that case only the first hit_capacity slots of the CSR were written and the caller
+ * repeats the call (or bivx_fill_dev) with a buffer of at least H entries. d_workspace must hold
+ * bivx_query_workspace_bytes(q) bytes and is overwritten. */
+size_t bivx_query_workspace_bytes(size_t q);
+int bivx_query_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                   const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hit_ids,
+                   uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes, void *stream);
 /* sorts every query's hit list ascending by id, in place */
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q,
                        void *stream);

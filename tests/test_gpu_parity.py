@@ -287,3 +287,72 @@ def test_config3_full_size_24_chroms_10M_x_10M_range(IntervalIndex, oracle):
     data = synth.gen_genome(10_000_000, 10_000_000, 1000, point_queries=False)
     H = _check_full(IntervalIndex, oracle, data, False)
     assert 25_000_000 < H < 40_000_000  # SURVEY §8d expects about 32 M
+
+
+# ---- single-pass kernel (bivx_query_dev) ---------------------------------------------------------------------
+
+def _fused(idx, torch, qlo_t, qhi_t, cap, qchrom_t=None):
+    q = qlo_t.numel()
+    off = torch.empty(q + 1, dtype=torch.int64, device=qlo_t.device)
+    hits = torch.full((max(cap, 1),), -1, dtype=torch.int32, device=qlo_t.device)
+    ws = torch.empty(idx.query_workspace_bytes(q), dtype=torch.uint8, device=qlo_t.device)
+    idx.query_device(qlo_t, qhi_t, off, hits, ws, qchrom=qchrom_t, sort_by_id=False)
+    torch.cuda.synchronize()
+    return off, hits
+
+
+def test_single_pass_equals_two_pass_and_oracle(IntervalIndex, oracle):
+    import torch
+    from binary_amd import synth
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    data = synth.gen_genome(300_000, 200_003, 1000)  # 24 chromosomes, ragged last tile
+    # a few long intervals and long queries so that both the lane path and the wavefront path run
+    rng = np.random.default_rng(4)
+    data["high"][:50] = data["low"][:50] + rng.integers(1_000_000, 50_000_000, size=50).astype(np.uint32)
+    data["qhigh"][:30] = data["qlow"][:30] + rng.integers(100_000, 5_000_000, size=30).astype(np.uint32)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(data["low"], data["high"], data["chrom"])
+        idx.build()
+        off2, hits2 = idx.find_overlaps(data["qlow"], data["qhigh"], data["qchrom"], sort_by_id=False)
+        H = int(off2[-1])
+        off1, hits1 = _fused(idx, torch, to(data["qlow"]), to(data["qhigh"]), H, to(data["qchrom"]))
+        # same CSR, same index order, bit for bit
+        assert np.array_equal(off1.cpu().numpy().astype(np.uint64), off2)
+        assert np.array_equal(hits1.cpu().numpy().view(np.uint32)[:H], hits2)
+        # capacity smaller than H: offsets still exact, the written prefix is exact, nothing beyond it is touched
+        cap = H // 3
+        off3, hits3 = _fused(idx, torch, to(data["qlow"]), to(data["qhigh"]), cap, to(data["qchrom"]))
+        assert np.array_equal(off3.cpu().numpy().astype(np.uint64), off2)
+        assert np.array_equal(hits3.cpu().numpy().view(np.uint32)[:cap], hits2[:cap])
+        # zero capacity: a pure count
+        off4, _ = _fused(idx, torch, to(data["qlow"]), to(data["qhigh"]), 0, to(data["qchrom"]))
+        assert int(off4[-1].item()) == H
+    # and the set is the reference's, chromosome by chromosome
+    for c in (0, 7, 23):
+        ii, qi = data["chrom"] == c, data["qchrom"] == c
+        t = oracle.OracleTree(data["low"][ii], data["high"][ii])
+        off_o, hits_o = t.find_overlaps_batch(data["qlow"][qi], data["qhigh"][qi])
+        assert np.array_equal(np.diff(off2.astype(np.int64))[qi], np.diff(off_o.astype(np.int64)))
+        sel = np.nonzero(ii)[0]
+        got = np.concatenate([np.sort(hits2[int(off2[k]):int(off2[k + 1])]) for k in np.nonzero(qi)[0]])
+        assert np.array_equal(got.astype(np.int64), sel[oracle.sorted_csr(off_o, hits_o)])
+
+
+def test_single_pass_repeated_calls_are_deterministic(IntervalIndex):
+    import torch
+    from binary_amd import synth
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    low, high = synth.gen_intervals(200_000, 20_000_000, 1000)
+    qlo, qhi = synth.gen_range_queries(150_001, 20_000_000, 1000)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        ref = None
+        for _ in range(5):
+            off, hits = _fused(idx, torch, to(qlo), to(qhi), 1_000_000)
+            cur = (off.cpu().numpy().copy(), hits.cpu().numpy()[: int(off[-1].item())].copy())
+            if ref is None:
+                ref = cur
+            assert np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1])
