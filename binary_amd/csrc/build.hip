@@ -19,7 +19,7 @@ __device__ __forceinline__ uint32_t len_bin(uint32_t low, uint32_t high, uint32_
 
 // ---- per (chromosome, length bin) statistics ---------------------------------------------------------
 
-constexpr uint32_t kStatsLdsEntries = 2048;  // (chrom, bin) pairs privatised in LDS (62 chromosomes)
+constexpr uint32_t kStatsLdsEntries = 1650;  // (chrom, bin) pairs privatised in LDS (50 chromosomes, 33 KB)
 
 template <bool USE_LDS>
 __global__ __launch_bounds__(kThreads) void k_bin_stats(const uint32_t *__restrict__ chrom,
@@ -29,17 +29,19 @@ __global__ __launch_bounds__(kThreads) void k_bin_stats(const uint32_t *__restri
   __shared__ BinStats lds[USE_LDS ? kStatsLdsEntries : 1];
   const uint32_t nent = nchrom * kLenBins;
   if (USE_LDS) {
-    for (uint32_t e = threadIdx.x; e < nent; e += kThreads) lds[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u};
+    for (uint32_t e = threadIdx.x; e < nent; e += kThreads) lds[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u, 0u};
     __syncthreads();
   }
   BinStats *tab = USE_LDS ? lds : stats;
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
     const uint32_t c = chrom ? chrom[i] : 0u;
     const uint32_t lo = low[i];
+    const uint32_t hi = high[i];
     uint32_t len;
-    const uint32_t b = len_bin(lo, high[i], len);
+    const uint32_t b = len_bin(lo, hi, len);
     BinStats *e = tab + (size_t)c * kLenBins + b;
     atomicAdd(&e->count, 1u);
+    if (lo > hi) atomicAdd(&e->n_inverted, 1u);
     atomicMin(&e->min_low, lo);
     atomicMax(&e->max_low, lo);
     atomicMax(&e->max_len, len);
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_stats(const uint32_t *__restri
         atomicMin(&stats[e].min_low, s.min_low);
         atomicMax(&stats[e].max_low, s.max_low);
         atomicMax(&stats[e].max_len, s.max_len);
+        if (s.n_inverted) atomicAdd(&stats[e].n_inverted, s.n_inverted);
       }
     }
   }
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_stats(const uint32_t *__restri
 
 __global__ __launch_bounds__(kThreads) void k_init_stats(BinStats *stats, uint32_t nent) {
   const uint32_t e = blockIdx.x * kThreads + threadIdx.x;
-  if (e < nent) stats[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u};
+  if (e < nent) stats[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u, 0u};
 }
 
 __global__ __launch_bounds__(kThreads) void k_max_u32(const uint32_t *__restrict__ in, size_t n,
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(kThreads) void k_build_table(const uint2 *__restric
   const uint32_t c = (uint32_t)(e - d.table_off);
   uint32_t a = d.begin, b = d.end;
   if (c < d.ncell) {
-    const uint32_t x = d.base + (c << d.shift);
+    const uint32_t x = d.base + (c << (d.shift & 31u));
     while (a < b) {
       const uint32_t m = (a + b) >> 1;
       if (se[m].x < x) a = m + 1; else b = m;
@@ -250,6 +253,30 @@ __global__ __launch_bounds__(kThreads) void k_build_table(const uint2 *__restric
     a = d.end;
   }
   table[e] = a;
+}
+
+// ---- packed records ----------------------------------------------------------------------------------------
+// rec[i] = ((low - cell_low) | (high - low) << 16, id) for slots of kSegPacked segments ((0, id) elsewhere)
+__global__ __launch_bounds__(kThreads) void k_pack_records(const uint2 *__restrict__ se,
+                                                           const uint32_t *__restrict__ id,
+                                                           const SegDesc *__restrict__ seg, uint32_t nseg,
+                                                           uint2 *__restrict__ rec, size_t n) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = nseg;  // last segment with begin <= i
+  while (hi - lo > 1) {
+    const uint32_t m = (lo + hi) >> 1;
+    if ((size_t)seg[m].begin <= i) lo = m; else hi = m;
+  }
+  const SegDesc d = seg[lo];
+  uint32_t r = 0;
+  if (d.shift & kSegPacked) {
+    const uint2 e = se[i];
+    const uint32_t sh = d.shift & 31u;
+    const uint32_t rel = e.x - d.base;
+    r = (rel - ((rel >> sh) << sh)) | ((e.y - e.x) << 16);
+  }
+  rec[i] = make_uint2(r, id[i]);
 }
 
 inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0) {
@@ -340,6 +367,15 @@ int launch_build_table(const uint2 *d_se, const SegDesc *d_seg, uint32_t nseg, u
   if (nentries == 0) return 0;
   hipLaunchKernelGGL(k_build_table, dim3(grid_for(nentries, kThreads)), dim3(kThreads), 0, s, d_se, d_seg, nseg,
                      d_table, nentries);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_pack_records(const uint2 *d_se, const uint32_t *d_id, const SegDesc *d_seg, uint32_t nseg, uint2 *d_rec,
+                        size_t n, hipStream_t s) {
+  if (n == 0 || nseg == 0) return 0;
+  hipLaunchKernelGGL(k_pack_records, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_se, d_id, d_seg, nseg, d_rec,
+                     n);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

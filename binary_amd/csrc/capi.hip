@@ -37,6 +37,7 @@ struct bivx_index {
   // built index
   bool built = false;
   uint2 *d_se = nullptr;
+  uint2 *d_rec = nullptr;
   uint32_t *d_id = nullptr;
   uint32_t *d_table = nullptr;
   SegDesc *d_seg = nullptr;
@@ -92,11 +93,13 @@ struct TempPool {
 
 void free_built(bivx_index *idx) {
   (void)hipFree(idx->d_se);
+  (void)hipFree(idx->d_rec);
   (void)hipFree(idx->d_id);
   (void)hipFree(idx->d_table);
   (void)hipFree(idx->d_seg);
   (void)hipFree(idx->d_chrom_seg);
   idx->d_se = nullptr;
+  idx->d_rec = nullptr;
   idx->d_id = nullptr;
   idx->d_table = nullptr;
   idx->d_seg = nullptr;
@@ -208,11 +211,12 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &pl
     for (int k = ns - 1; k >= 0; --k) {
       const int i0 = starts[k], i1 = (k == 0) ? m : starts[k - 1];
       SegDesc d{};
-      uint64_t cnt = 0;
+      uint64_t cnt = 0, ninv = 0;
       uint32_t mn = 0xFFFFFFFFu, mx = 0, ml = 0;
       for (int i = i0; i < i1; ++i) {
         const BinStats &s = st[(size_t)c * kLenBins + bins[i]];
         cnt += s.count;
+        ninv += s.n_inverted;
         mn = s.min_low < mn ? s.min_low : mn;
         mx = s.max_low > mx ? s.max_low : mx;
         ml = s.max_len > ml ? s.max_len : ml;
@@ -228,6 +232,7 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &pl
       uint32_t sh = 0;
       while (sh < 31 && (span >> sh) + 1 > target) ++sh;
       d.shift = sh;
+      if (sh <= 16 && ml <= 0xFFFFu && ninv == 0) d.shift |= kSegPacked;
       d.ncell = (uint32_t)((span >> sh) + 1);
       if (table_off + d.ncell + 1 > 0xFFFFFFFFull) {
         set_error("bucket directory too large");
@@ -257,6 +262,7 @@ int bits_for(uint32_t maxval) {
 IndexView view_of(const bivx_index *idx) {
   IndexView v;
   v.se = idx->d_se;
+  v.rec = idx->d_rec;
   v.id = idx->d_id;
   v.table = idx->d_table;
   v.seg = idx->d_seg;
@@ -434,8 +440,14 @@ int bivx_build(bivx_index *idx) {
     idx->d_id = vA;
     tmp.release(vA);
     // 7. bucket directory
-    BIVX_HIP(hipMalloc((void **)&idx->d_table, (size_t)plan.nentries * 4));
+    // (+3 spare entries: query lanes read directory entries four at a time)
+    BIVX_HIP(hipMalloc((void **)&idx->d_table, ((size_t)plan.nentries + 3) * 4));
+    BIVX_HIP(hipMemsetAsync(idx->d_table + plan.nentries, 0xFF, 3 * 4, s));
     BIVX_TRY(launch_build_table(idx->d_se, idx->d_seg, nseg, idx->d_table, plan.nentries, s));
+    // 8. packed (record, id) pairs for the segments that allow them (+2 spare: read two at a time)
+    BIVX_HIP(hipMalloc((void **)&idx->d_rec, (n + 2) * sizeof(uint2)));
+    BIVX_HIP(hipMemsetAsync(idx->d_rec + n, 0, 2 * sizeof(uint2), s));
+    BIVX_TRY(launch_pack_records(idx->d_se, idx->d_id, idx->d_seg, nseg, idx->d_rec, n, s));
   }
   BIVX_HIP(hipStreamSynchronize(s));
   idx->nchrom = nchrom;
@@ -664,7 +676,7 @@ int bivx_get_stats(const bivx_index *idx, bivx_stats *out) {
   out->n_cells = idx->nentries;
   out->staging_bytes = (uint64_t)idx->cap * 12;
   if (idx->built)
-    out->index_bytes = (uint64_t)idx->built_n * 12 + idx->nentries * 4 + (uint64_t)idx->nseg * sizeof(SegDesc) +
+    out->index_bytes = (uint64_t)idx->built_n * 20 + idx->nentries * 4 + (uint64_t)idx->nseg * sizeof(SegDesc) +
                        ((uint64_t)idx->nchrom + 1) * 4;
   out->build_ms = idx->build_ms;
   return 0;

@@ -35,16 +35,20 @@ constexpr int kLenBins = 33;       // bin 0: len == 0 (incl. low > high); bin b:
 struct SegDesc {        // 32 B, read as two dwordx4
   uint32_t begin, end;  // element range [begin, end) in se[] / id[]
   uint32_t base, last;  // min / max `low` in the segment
-  uint32_t shift;       // directory cell of coordinate x: (x - base) >> shift
+  uint32_t shift;       // bits 0-4: directory cell of coordinate x is (x - base) >> shift; bit 8: kSegPacked
   uint32_t table_off;   // first directory entry; the segment owns ncell + 1 entries
   uint32_t maxlen;      // max over the segment of (high >= low ? high - low : 0)
   uint32_t ncell;
 };
 static_assert(sizeof(SegDesc) == 32, "SegDesc layout");
+// Segment also has packed records rec[i] = ((low - cell_low) | (high - low) << 16, id): needs shift <= 16,
+// maxlen <= 65535 and no low > high entry.
+constexpr uint32_t kSegPacked = 1u << 8;
 
 // Device view of a built index, passed to kernels by value.
 struct IndexView {
   const uint2 *se;            // (low, high) sorted by (segment, low, id)
+  const uint2 *rec;           // packed (record, id) pairs (meaningful in kSegPacked segments only)
   const uint32_t *id;         // append-order id of each sorted slot
   const uint32_t *table;      // bucket directories, all segments back to back
   const SegDesc *seg;         // nseg descriptors, grouped by chromosome
@@ -59,6 +63,7 @@ struct BinStats {
   uint32_t min_low;
   uint32_t max_low;
   uint32_t max_len;
+  uint32_t n_inverted;  // entries with low > high
 };
 
 // ---- scan.hip ---------------------------------------------------------------------------------------
@@ -83,6 +88,8 @@ int launch_gather_se(const uint32_t *d_low, const uint32_t *d_high, const uint32
                      size_t n, hipStream_t s);
 int launch_build_table(const uint2 *d_se, const SegDesc *d_seg, uint32_t nseg, uint32_t *d_table,
                        uint64_t ncells_total, hipStream_t s);
+int launch_pack_records(const uint2 *d_se, const uint32_t *d_id, const SegDesc *d_seg, uint32_t nseg, uint2 *d_rec,
+                        size_t n, hipStream_t s);
 int launch_gather_intervals(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
                             const uint32_t *d_ids, size_t n, size_t n_intervals, uint32_t *d_c, uint32_t *d_l,
                             uint32_t *d_h, hipStream_t s);

@@ -1,18 +1,21 @@
 // query.hip — batched overlap queries against the built index (gfx950, wave64).
 //
 // Replaces IntervalTree::find_overlaps / find_overlap (reference interval_tree.hpp:290-334) for a batch.
-// One lane per query. Per (chromosome, length class) segment ONE bucket-directory load gives the slot to
-// start from: the first slot of the cell holding x = q.low - maxlen. The lane then walks the start-sorted
-// (low, high) pairs while low <= q.high and tests q.low <= high on each; slots before x need no separate
-// search because low < q.low - maxlen implies high < q.low. Walks longer than kLight slots are finished by
-// the whole wavefront (coalesced loads, __ballot compaction), so a chromosome-scale query costs
-// O(window / 64) wave steps instead of stalling one lane.
-//
+// One lane per query. Per (chromosome, length class) segment ONE 16-byte bucket-directory load bounds the
+// candidate window [a, b): a = first slot of the cell holding x = q.low - maxlen, b = end of the cell
+// holding q.high. Every candidate is then tested with the reference predicate low <= q.high &&
+// q.low <= high; no binary search is needed because slots outside [x, q.high] fail the predicate by
+// themselves. All candidate loads are independent of each other (16-byte loads, several in flight).
+//   - packed segments: 8-byte records (16-bit offset in cell | 16-bit length, id), two per load: the line that
+//     says "hit" also carries the id
+//   - other segments:  8-byte (low, high) pairs, two per load; ids in a parallel array
+//   - windows longer than kLight slots are read by the whole wavefront (coalesced rows, __ballot compaction),
+//     so a chromosome-scale query costs O(window / 64) wave steps instead of stalling one lane
 // Segment descriptors are staged through LDS. Integer compare/index work only: no MFMA anywhere.
 //
 // Two ways in:  k_query<Count|Fill|Any>  (two-pass API: count -> offsets scan -> fill), and
-//               k_query_fused            (single pass: count, chained prefix across workgroups with a
-//                                         decoupled look-back, then fill into a caller-sized buffer).
+//               k_query_fused            (single pass: count, prefix across workgroups, fill into a
+//                                         caller-sized buffer).
 #include "common.h"
 
 namespace bivx {
@@ -24,6 +27,8 @@ constexpr uint32_t kLight = 32;      // window slots a lane reads by itself; lon
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
 constexpr uint32_t kLdsChroms = 511; // ... with chrom_seg (2 KiB); larger indexes read them from global
 
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
 __device__ __forceinline__ SegDesc load_seg(const SegDesc *p) {
   const uint4 *q = reinterpret_cast<const uint4 *>(p);
   const uint4 u = q[0], w = q[1];
@@ -33,24 +38,34 @@ __device__ __forceinline__ SegDesc load_seg(const SegDesc *p) {
   return d;
 }
 
-// Candidate window [a, b) of query [lo, hi] in segment d, straight from the bucket directory with no
-// refinement: a = first slot of the cell holding x = lo - maxlen, b = one past the last slot of the cell
-// holding hi. Every hit has low <= hi and low >= high - maxlen >= lo - maxlen (entries with low > high count
-// as length 0 and obey the same bound), so all hits are inside; slots of the two edge cells that are not hits
-// fail `low <= hi && high >= lo`, which is evaluated on every candidate anyway. The two directory loads are
-// independent of each other, and so are all candidate loads once a and b are known.
-__device__ __forceinline__ void seg_window(const IndexView &v, const SegDesc &d, uint32_t lo, uint32_t hi,
-                                           uint32_t &a, uint32_t &b) {
+// Candidate window of query [lo, hi] in one segment, straight from the bucket directory.
+// Every hit has low <= hi and low >= high - maxlen >= lo - maxlen (entries with low > high count as length 0
+// and obey the same bound), so all hits lie in the cells ca .. cb-1; slots of the two edge cells that are
+// not hits fail the predicate, which is evaluated on every candidate anyway.
+struct Window {
+  uint32_t a, b;        // candidate slots [a, b)
+  uint32_t t1, t2;      // first slots of cells ca+1, ca+2 (valid when span <= 3)
+  uint32_t cell0_low;   // coordinate of the start of cell ca
+  uint32_t span;        // number of cells, 0 = empty window
+};
+
+__device__ __forceinline__ Window seg_window(const IndexView &v, const SegDesc &d, uint32_t lo, uint32_t hi) {
+  Window w{0u, 0u, 0u, 0u, 0u, 0u};
   const uint32_t x = lo > d.maxlen ? lo - d.maxlen : 0u;
-  if (hi < d.base || x > d.last) {
-    a = b = d.end;
-    return;
-  }
+  if (hi < d.base || x > d.last || hi < x) return w;
+  const uint32_t sh = d.shift & 31u;
   const uint32_t *t = v.table + d.table_off;
-  const uint32_t ca = x <= d.base ? 0u : (x - d.base) >> d.shift;
-  const uint32_t cb = hi >= d.last ? d.ncell : ((hi - d.base) >> d.shift) + 1u;
-  a = t[ca];  // t[0] == d.begin, t[ncell] == d.end
-  b = t[cb];
+  const uint32_t ca = x <= d.base ? 0u : (x - d.base) >> sh;
+  const uint32_t cb = hi >= d.last ? d.ncell : ((hi - d.base) >> sh) + 1u;
+  // directory entries ca .. ca+3 in one 16-byte load (4-byte aligned; the table carries 3 spare entries)
+  const u32x4_a4 tq = *reinterpret_cast<const u32x4_a4 *>(t + ca);
+  w.span = cb - ca;
+  w.a = tq.x;
+  w.t1 = tq.y;
+  w.t2 = tq.z;
+  w.b = w.span == 1 ? tq.y : w.span == 2 ? tq.z : w.span == 3 ? tq.w : t[cb];
+  w.cell0_low = d.base + (ca << sh);
+  return w;
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
@@ -64,6 +79,80 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t x) {
   return x;
 }
 
+// hit mask of a short window over 8-byte (low, high) pairs; bit j <-> slot al + j, al = a rounded down to 2
+__device__ __forceinline__ uint32_t light_mask_pairs(const IndexView &v, uint32_t a, uint32_t b, uint32_t lo,
+                                                     uint32_t hi, uint32_t &al) {
+  const uint4 *pairs = reinterpret_cast<const uint4 *>(v.se);
+  al = a & ~1u;
+  uint32_t mask = 0;
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < kLight; c0 += 8) {
+    if (al + c0 < b) {
+      uint4 r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t s = al + c0 + 2 * j;
+        if (s < b) r[j] = pairs[s >> 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t s = al + c0 + 2 * j;
+        if (s < b) {
+          if (s >= a && r[j].x <= hi && r[j].y >= lo) mask |= 1u << (c0 + 2 * j);
+          if (s + 1 < b && r[j].z <= hi && r[j].w >= lo) mask |= 1u << (c0 + 2 * j + 1);
+        }
+      }
+    }
+  }
+  return mask;
+}
+
+// the same over packed records of a window of at most 3 cells. A packed record is 8 bytes:
+// (off16 | len16 << 16, id) — the interval relative to its directory cell, and its append-order id right
+// beside it, so the cache line that answers "is it a hit" also says which interval it is.
+// bit j <-> slot al + j, al = a rounded down to 2. If `keep` is given, the ids of the first kKeep hits are
+// written there (ascending slot order) as they are found; *nkept receives min(hits, kKeep).
+constexpr uint32_t kKeep = 4;
+__device__ __forceinline__ uint32_t light_mask_packed(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
+                                                      uint32_t hi, uint32_t &al, uint32_t *keep) {
+  const uint4 *pairs = reinterpret_cast<const uint4 *>(v.rec);
+  al = w.a & ~1u;
+  uint32_t mask = 0, n = 0;
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < kLight; c0 += 8) {
+    if (al + c0 < w.b) {
+      uint4 r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t s = al + c0 + 2 * j;
+        if (s < w.b) r[j] = pairs[s >> 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t s = al + c0 + 2 * j;
+        if (s < w.b) {
+          const uint32_t rr[2] = {r[j].x, r[j].z}, ii[2] = {r[j].y, r[j].w};
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const uint32_t i = s + e;
+            const uint32_t cell = (i >= w.t1 ? 1u : 0u) + (i >= w.t2 ? 1u : 0u);
+            const uint32_t low = w.cell0_low + (cell << sh) + (rr[e] & 0xFFFFu);
+            const uint32_t high = low + (rr[e] >> 16);
+            if (i >= w.a && i < w.b && low <= hi && high >= lo) {
+              mask |= 1u << (c0 + 2 * j + e);
+              if (keep) {
+                if (n < kKeep) keep[n] = ii[e];
+                ++n;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  return mask;
+}
+
 enum class Mode { Count, Fill, Any };
 
 // Per-lane query state shared by every kernel.
@@ -72,74 +161,65 @@ struct Query {
   uint32_t s0, nseg;  // segments [s0, s0 + nseg) of the query's chromosome
 };
 
-// What a lane remembers from a counting walk so that the fill needs no second look at (low, high):
+// What a lane remembers from a counting pass so that the fill needs no second look at the intervals:
 // valid when the query touched one segment and its window fitted the lane budget.
 struct Replay {
-  uint32_t a2;    // even-aligned first slot of the window
-  uint32_t mask;  // bit j set: slot a2 + j is a hit
+  uint32_t al;    // aligned first slot of the window
+  uint32_t mask;  // bit j set: slot al + j is a hit
   bool ok;
+  bool kept;      // ids of the first min(hits, kKeep) hits were written to the caller's `keep` slots
 };
 
 // The whole hit enumeration of one query per lane, wavefront-converged (all 64 lanes must call it).
 //   Count: returns the number of hits (and fills *rp).   Any: returns the smallest hit id (BIVX_NO_HIT if none).
 //   Fill:  writes hit ids to hits_base[dst_pos ..), in index order, only positions below `cap`;
 //          returns the number of hits.
-// Lane budget: windows of at most kLight slots are read by the lane itself, two slots per 16-byte load and
-// four loads in flight; longer windows are read by the whole wavefront, one coalesced 512-byte row per step.
 template <Mode M>
 __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const SegDesc *segs, const Query &qy,
                                                    uint32_t *hits_base, uint64_t dst_pos, uint64_t cap,
-                                                   Replay *rp) {
+                                                   Replay *rp, uint32_t *keep = nullptr) {
   const int lane = threadIdx.x & (kWave - 1);
   uint32_t acc = (M == Mode::Any) ? BIVX_NO_HIT : 0u;
   const uint32_t lo = qy.lo, hi = qy.hi;
-  const uint4 *pairs = reinterpret_cast<const uint4 *>(v.se);
   if (M == Mode::Count && rp) {
-    rp->a2 = 0;
+    rp->al = 0;
     rp->mask = 0;
     rp->ok = qy.nseg <= 1;
+    rp->kept = false;
   }
   // the segment loop is wavefront-uniform so the cooperative part may use __ballot / __shfl
   for (uint32_t k = 0; __any(k < qy.nseg); ++k) {
-    uint32_t a = 0, b = 0;
+    Window w{0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t shf = 0;
     if (k < qy.nseg) {
       const SegDesc d = load_seg(segs + qy.s0 + k);
-      seg_window(v, d, lo, hi, a, b);
+      w = seg_window(v, d, lo, hi);
+      shf = d.shift;
     }
-    const uint32_t a2 = a & ~1u;
-    const bool heavy = b > a && (b - a2) > kLight;
-    if (b > a && !heavy) {
-      uint32_t mask = 0;
-#pragma unroll
-      for (uint32_t c0 = 0; c0 < kLight; c0 += 8) {
-        if (a2 + c0 < b) {
-          uint4 r[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t s = a2 + c0 + 2 * j;
-            if (s < b) r[j] = pairs[s >> 1];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t s = a2 + c0 + 2 * j;
-            if (s < b) {
-              if (s >= a && r[j].x <= hi && r[j].y >= lo) mask |= 1u << (c0 + 2 * j);
-              if (s + 1 < b && r[j].z <= hi && r[j].w >= lo) mask |= 1u << (c0 + 2 * j + 1);
-            }
-          }
-        }
+    const bool nonempty = w.span != 0 && w.b > w.a;
+    const bool packed = (shf & kSegPacked) != 0 && w.span <= 3;
+    const bool heavy = nonempty && (w.b - (w.a & ~1u)) > kLight;
+    if (nonempty && !heavy) {
+      uint32_t al;
+      uint32_t mask;
+      if (packed) {
+        const bool want = M == Mode::Count && keep != nullptr && qy.nseg == 1;
+        mask = light_mask_packed(v, w, shf & 31u, lo, hi, al, want ? keep : nullptr);
+        if (M == Mode::Count && rp) rp->kept = want;
+      } else {
+        mask = light_mask_pairs(v, w.a, w.b, lo, hi, al);
       }
       if (M == Mode::Count) {
         acc += (uint32_t)__popc(mask);
         if (rp) {
-          rp->a2 = a2;
+          rp->al = al;
           rp->mask = mask;
         }
       } else {
         while (mask) {
           const uint32_t j = (uint32_t)__ffs((int)mask) - 1u;
           mask &= mask - 1;
-          const uint32_t hid = v.id[a2 + j];
+          const uint32_t hid = packed ? v.rec[al + j].y : v.id[al + j];  // packed: the line is already here
           if (M == Mode::Any) acc = min(acc, hid);
           if (M == Mode::Fill) {
             if (dst_pos + acc < cap) hits_base[dst_pos + acc] = hid;
@@ -153,7 +233,7 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
     while (hm) {
       const int src = __ffsll((long long)hm) - 1;
       hm &= hm - 1;
-      const uint32_t ca = __shfl(a, src, kWave), cb = __shfl(b, src, kWave);
+      const uint32_t ca = __shfl(w.a, src, kWave), cb = __shfl(w.b, src, kWave);
       const uint32_t cl = __shfl(lo, src, kWave), ch = __shfl(hi, src, kWave);
       if (M == Mode::Count) {
         uint32_t c = 0;
@@ -203,8 +283,8 @@ __device__ __forceinline__ void stage_descriptors(const IndexView &v, SegDesc *s
   if (LDS_DESC) {
     const uint4 *src = reinterpret_cast<const uint4 *>(v.seg);
     uint4 *dst = reinterpret_cast<uint4 *>(s_seg);
-    for (uint32_t t = threadIdx.x; t < v.nseg * 2; t += kQThreads) dst[t] = src[t];
-    for (uint32_t t = threadIdx.x; t <= v.nchrom; t += kQThreads) s_cs[t] = v.chrom_seg[t];
+    for (uint32_t t = threadIdx.x; t < v.nseg * 2; t += blockDim.x) dst[t] = src[t];
+    for (uint32_t t = threadIdx.x; t <= v.nchrom; t += blockDim.x) s_cs[t] = v.chrom_seg[t];
     segs = s_seg;
     cs = s_cs;
   } else {
@@ -251,12 +331,29 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
 }
 
 // ---- single-pass kernel ----------------------------------------------------------------------------------
-// ws[0] (low 32 bits): tile ticket; ws[1 + t]: status of tile t = state << 62 | value, written and polled as
-// ONE 8-byte agent-scope atomic so the value needs no separate fence (per-XCD L2s are not coherent; sc1
-// accesses go to memory). state 1 = tile aggregate, 2 = inclusive prefix. Tiles take tickets in launch order,
-// so every predecessor of a polling tile is already resident: the chain cannot deadlock. Spins are bounded.
-constexpr uint64_t kStAgg = 1ull << 62, kStInc = 2ull << 62, kStMask = 3ull << 62;
-constexpr uint32_t kSpinCap = 1u << 22;
+// A workgroup owns kFTile = 1024 consecutive queries, four per thread. It counts them (remembering each short
+// window's hit mask), publishes its hit total, sums the totals of ALL earlier tiles, then writes offsets and
+// hit ids. One launch has at most kFMaxTiles tiles, so the prefix is a sweep over at most 1023 status words
+// (16 loads per lane, issued four at a time) instead of a serial look-back chain: on MI355X every poll of
+// another XCD's status word goes to memory (per-XCD L2s are not coherent), so the number of dependent polls,
+// not their width, is what costs. Larger batches run as consecutive launches; each starts from the running
+// total its predecessor left in offsets[q_begin].
+//   ws[0] (low 32 bits): tile ticket. ws[1 + t]: kStValid | hits of tile t, written and polled as ONE 8-byte
+//   agent-scope atomic, so the value needs no separate fence. Tiles take tickets in launch order: every
+//   predecessor of a polling tile is already resident, the wait cannot deadlock; spins are bounded anyway.
+#ifndef BIVX_FUSED_THREADS
+#define BIVX_FUSED_THREADS 512
+#endif
+#ifndef BIVX_FUSED_ROUNDS
+#define BIVX_FUSED_ROUNDS 2
+#endif
+constexpr int kFThreads = BIVX_FUSED_THREADS;
+constexpr int kFWaves = kFThreads / kWave;
+constexpr int kFR = BIVX_FUSED_ROUNDS;  // consecutive queries per thread
+constexpr int kFTile = kFThreads * kFR;
+constexpr unsigned kFMaxTiles = 1024;
+constexpr uint64_t kStValid = 1ull << 63;
+constexpr uint32_t kSpinCap = 1u << 20;
 
 __device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -266,17 +363,18 @@ __device__ __forceinline__ void st_status(uint64_t *p, uint64_t w) {
 }
 
 template <bool LDS_DESC>
-__global__ __launch_bounds__(kQThreads) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
+__global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
-                                                           const uint32_t *__restrict__ qhigh, size_t nq,
-                                                           uint64_t *__restrict__ offsets,
+                                                           const uint32_t *__restrict__ qhigh, size_t q_begin,
+                                                           size_t q_end, uint64_t *__restrict__ offsets,
                                                            uint32_t *__restrict__ hits, uint64_t cap,
                                                            uint64_t *__restrict__ ws) {
   __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
   __shared__ uint32_t s_cs[LDS_DESC ? kLdsChroms + 1 : 1];
   __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_wsum[kQWaves];
+  __shared__ uint32_t s_wsum[kFWaves];
   __shared__ uint64_t s_base;
+  __shared__ uint4 s_keep[kFR][kFThreads];  // ids of each query's first kKeep hits (thread-private slots)
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
@@ -288,16 +386,22 @@ __global__ __launch_bounds__(kQThreads) void k_query_fused(IndexView v, const ui
   const uint32_t tile = s_tile;
   uint64_t *status = ws + 1;
 
-  const size_t q = (size_t)tile * kQThreads + threadIdx.x;
-  const bool valid = q < nq;
-  const Query qy = load_query(v, cs, qchrom, qlow, qhigh, q, valid);
+  // phase 1: count the thread's four consecutive queries
+  const size_t q0 = q_begin + ((size_t)tile * kFThreads + threadIdx.x) * kFR;
+  Query qy[kFR];
+  Replay rp[kFR];
+  uint32_t cnt[kFR];
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int r = 0; r < kFR; ++r) {
+    qy[r] = load_query(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
+    cnt[r] = enumerate_hits<Mode::Count>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
+                                         reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x]));
+    tsum += cnt[r];
+  }
 
-  // phase 1: count
-  Replay rp;
-  const uint32_t cnt = enumerate_hits<Mode::Count>(v, segs, qy, nullptr, 0, 0, &rp);
-
-  // workgroup exclusive scan of the counts
-  uint32_t incl = cnt;
+  // workgroup exclusive scan of the per-thread sums
+  uint32_t incl = tsum;
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
     const uint32_t o = __shfl_up(incl, d, kWave);
@@ -307,74 +411,91 @@ __global__ __launch_bounds__(kQThreads) void k_query_fused(IndexView v, const ui
   __syncthreads();
   uint32_t wbase = 0, total = 0;
 #pragma unroll
-  for (int w = 0; w < kQWaves; ++w) {
+  for (int w = 0; w < kFWaves; ++w) {
     const uint32_t s = s_wsum[w];
     if (w < wave) wbase += s;
     total += s;
   }
-  const uint32_t local = wbase + incl - cnt;
+  const uint32_t local = wbase + incl - tsum;
 
-  // chained prefix across tiles: wave 0 publishes the aggregate, looks back, publishes the inclusive prefix
+  // prefix across tiles: wave 0 publishes this tile's total and sums every earlier tile's
   if (wave == 0) {
-    uint64_t excl = 0;
-    if (tile == 0) {
-      if (lane == 0) st_status(&status[0], kStInc | (uint64_t)total);
-    } else {
-      if (lane == 0) st_status(&status[tile], kStAgg | (uint64_t)total);
-      int64_t look = (int64_t)tile - 1;
-      uint32_t spins = 0;
-      while (true) {
-        const int64_t t = look - lane;
-        uint64_t w = kStInc;  // tiles before 0: inclusive prefix 0
-        if (t >= 0) w = ld_status(&status[t]);
-        while (__any((w & kStMask) == 0) && spins < kSpinCap) {
-          __builtin_amdgcn_s_sleep(2);
-          if ((w & kStMask) == 0) w = ld_status(&status[t]);
+    if (lane == 0) st_status(&status[tile], kStValid | (uint64_t)total);
+    uint64_t sum = 0;
+    for (uint32_t t0 = 0; t0 < tile; t0 += 4 * kWave) {
+      uint64_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t t = t0 + j * kWave + lane;
+        w[j] = t < tile ? ld_status(&status[t]) : kStValid;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t t = t0 + j * kWave + lane;
+        uint32_t spins = 0;
+        while (!(w[j] & kStValid) && spins < kSpinCap) {  // bounded: a wrong prefix beats a hung GPU
+          __builtin_amdgcn_s_sleep(1);
+          w[j] = ld_status(&status[t]);
           ++spins;
         }
-        const uint64_t inc_mask = __ballot((w & kStMask) == kStInc);
-        const uint64_t val = w & ~kStMask;
-        if (inc_mask) {
-          const int first = __ffsll((long long)inc_mask) - 1;
-          uint64_t part = lane <= first ? val : 0ull;
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) part += __shfl_xor((unsigned long long)part, d, kWave);
-          excl += part;
-          break;
-        }
-        uint64_t part = val;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor((unsigned long long)part, d, kWave);
-        excl += part;
-        look -= kWave;
-        if (spins >= kSpinCap) break;  // never expected; leaves a wrong prefix instead of a hung GPU
+        sum += w[j] & ~kStValid;
       }
-      if (lane == 0) st_status(&status[tile], kStInc | (excl + total));
     }
-    if (lane == 0) s_base = excl;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor((unsigned long long)sum, d, kWave);
+    if (lane == 0) s_base = sum + (q_begin ? offsets[q_begin] : 0ull);
   }
   __syncthreads();
-  const uint64_t pos = s_base + local;
-  if (valid) {
-    offsets[q] = pos;
-    if (q == nq - 1) offsets[nq] = pos + cnt;
-  }
 
-  // phase 2: fill. A lane whose walk was recorded replays the hit mask (ids only, no second look at the
-  // (low, high) pairs); the others enumerate again with the lines of phase 1 still in this CU's L1/L2.
-  if (rp.ok) {
-    uint32_t mask = rp.mask, k = 0;
-    while (mask) {
-      const uint32_t j = (uint32_t)__ffs((int)mask) - 1u;
-      mask &= mask - 1;
-      const uint32_t hid = v.id[rp.a2 + j];
-      if (pos + k < cap) hits[pos + k] = hid;
-      ++k;
+  // phase 2: offsets and hit ids. A query whose window was recorded replays its hit mask (ids only); the
+  // others enumerate again with the lines of phase 1 still in this CU's L1 / this XCD's L2.
+  uint64_t pos = s_base + local;
+#pragma unroll
+  for (int r = 0; r < kFR; ++r) {
+    const size_t q = q0 + r;
+    if (q < q_end) {
+      offsets[q] = pos;
+      if (q == q_end - 1) offsets[q_end] = pos + cnt[r];
     }
+    if (rp[r].ok) {
+      uint32_t mask = rp[r].mask, k = 0;
+      if (rp[r].kept) {
+        // the first kKeep ids were captured while counting: no load at all for most queries
+        const uint4 h = s_keep[r][threadIdx.x];
+        const uint32_t hh[4] = {h.x, h.y, h.z, h.w};
+        const uint32_t n = cnt[r] < kKeep ? cnt[r] : kKeep;
+#pragma unroll
+        for (uint32_t e = 0; e < kKeep; ++e) {
+          if (e < n) {
+            if (pos + e < cap) hits[pos + e] = hh[e];
+            mask &= mask - 1;
+          }
+        }
+        k = n;
+      }
+      // (remaining) ids four at a time: the loads of one group are independent of each other
+      while (mask) {
+        uint32_t j[4], hid[4];
+        int n = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          j[e] = mask ? (uint32_t)__ffs((int)mask) - 1u : 0u;
+          if (mask) ++n;
+          mask &= mask - 1;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < n) hid[e] = v.id[rp[r].al + j[e]];  // v.id mirrors the ids of the packed records
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < n && pos + k + e < cap) hits[pos + k + e] = hid[e];
+        k += n;
+      }
+      qy[r].nseg = 0;
+    }
+    (void)enumerate_hits<Mode::Fill>(v, segs, qy[r], hits, pos, cap, nullptr);
+    pos += cnt[r];
   }
-  Query q2 = qy;
-  if (rp.ok) q2.nseg = 0;
-  (void)enumerate_hits<Mode::Fill>(v, segs, q2, hits, pos, cap, nullptr);
 }
 
 // ---- per-query ascending-id ordering of a CSR hit list ------------------------------------------------
@@ -501,7 +622,10 @@ int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_q
   return launch_query<Mode::Any>(v, d_qchrom, d_qlow, d_qhigh, q, nullptr, d_first, s);
 }
 
-size_t fused_workspace_bytes(size_t q) { return ((size_t)tiles_for(q) + 2) * sizeof(uint64_t); }
+size_t fused_workspace_bytes(size_t q) {
+  (void)q;
+  return ((size_t)kFMaxTiles + 2) * sizeof(uint64_t);
+}
 
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
@@ -510,14 +634,19 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     BIVX_HIP(hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), s));
     return 0;
   }
-  BIVX_HIP(hipMemsetAsync(d_ws, 0, fused_workspace_bytes(q), s));  // ticket + tile status words
   uint64_t *ws = static_cast<uint64_t *>(d_ws);
-  if (fits_lds(v))
-    hipLaunchKernelGGL((k_query_fused<true>), dim3(tiles_for(q)), dim3(kQThreads), 0, s, v, d_qchrom, d_qlow,
-                       d_qhigh, q, d_offsets, d_hits, cap, ws);
-  else
-    hipLaunchKernelGGL((k_query_fused<false>), dim3(tiles_for(q)), dim3(kQThreads), 0, s, v, d_qchrom, d_qlow,
-                       d_qhigh, q, d_offsets, d_hits, cap, ws);
+  const size_t per_launch = (size_t)kFMaxTiles * kFTile;
+  for (size_t q0 = 0; q0 < q; q0 += per_launch) {
+    const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
+    const unsigned tiles = (unsigned)((q1 - q0 + kFTile - 1) / kFTile);
+    BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + 1) * sizeof(uint64_t), s));  // ticket + status words
+    if (fits_lds(v))
+      hipLaunchKernelGGL((k_query_fused<true>), dim3(tiles), dim3(kFThreads), 0, s, v, d_qchrom, d_qlow, d_qhigh, q0,
+                         q1, d_offsets, d_hits, cap, ws);
+    else
+      hipLaunchKernelGGL((k_query_fused<false>), dim3(tiles), dim3(kFThreads), 0, s, v, d_qchrom, d_qlow, d_qhigh, q0,
+                         q1, d_offsets, d_hits, cap, ws);
+  }
   BIVX_HIP(hipGetLastError());
   return 0;
 }
