@@ -1,0 +1,253 @@
+// tests/cpp/test_facade.cpp — the reference's own IntervalTree / RbTree test cases
+// (test/source/test_algorithm/test_interval_tree.cpp, test_rb_tree.cpp), re-expressed against the drop-in
+// headers in include/binary/algorithm/. Same inputs, same expected values; doctest is not in this image, so
+// a ten-line CHECK harness stands in. Overlap queries run on the GPU through libbivx.so.
+//
+//   usage: test_facade [--no-gpu]     (--no-gpu runs only the host-side structure cases)
+#include <algorithm>
+#include <array>
+#include <binary/algorithm/all.hpp>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <random>
+#include <stdexcept>
+#include <vector>
+
+using namespace binary::algorithm::tree;
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                      \
+  do {                                                                   \
+    ++g_checks;                                                          \
+    if (!(cond)) {                                                       \
+      ++g_fail;                                                          \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);        \
+    }                                                                    \
+  } while (0)
+#define CHECK_EQ(a, b) CHECK((a) == (b))
+
+template <typename P> int black_height(P root) {  // test_interval_tree.cpp:18-29
+  if (root == nullptr) return 0;
+  int l = black_height(root->leftr());
+  if (l != black_height(root->rightr())) throw std::invalid_argument("black height mismatch");
+  return static_cast<int>(root->is_black()) + l;
+}
+
+static const std::array<UIntInterval, 10> kFixture{
+    UIntInterval(16u, 21u), UIntInterval(8u, 9u),   UIntInterval(5u, 8u),   UIntInterval(0u, 3u),
+    UIntInterval(6u, 10u),  UIntInterval(15u, 23u), UIntInterval(25u, 30u), UIntInterval(17u, 19u),
+    UIntInterval(19u, 20u), UIntInterval(26u, 26u)};
+
+static void host_side_cases() {
+  {  // construct interval / node (test_interval_tree.cpp:31-72)
+    UIntInterval a{};
+    CHECK_EQ(a.low, 0u);
+    CHECK_EQ(a.high, 0u);
+    UIntInterval b{1, 2};
+    CHECK_EQ(b.low, 1u);
+    CHECK_EQ(b.high, 2u);
+    UIntIntervalNode n1{1u, 10u};
+    CHECK_EQ(n1.interval.low, 1u);
+    CHECK_EQ(n1.interval.high, 10u);
+    CHECK_EQ(n1.max, 10u);
+    UIntInterval c{100u, 2000u};
+    UIntIntervalNode n2{c};
+    CHECK_EQ(n2.interval.high, 2000u);
+    CHECK_EQ(n2.max, 2000u);
+    UIntIntervalNode n3{{1u, 20u}};
+    CHECK_EQ(n3.max, 20u);
+    IntervalNode<IntInterval> n4{1, 10};
+    CHECK_EQ(n4.interval.low, 1);
+    CHECK_EQ(n4.max, 10);
+  }
+  {  // RbTree<IntNode> (test_rb_tree.cpp:128-207)
+    RbTree<IntNode> t{};
+    for (auto k : {1, 2, 4}) t.insert_node(std::make_unique<IntNode>(k));
+    CHECK_EQ(t.size(), 3u);
+    CHECK_EQ(t.root()->key, 2);
+    CHECK_EQ(black_height(t.root()), 1);
+    auto *root = t.root();
+    CHECK_EQ(t.successor(root)->key, 4);
+    CHECK_EQ(t.predecessor(root)->key, 1);
+    CHECK(root->leftr()->parent == root && root->rightr()->parent == root);
+
+    RbTree<IntNode> t5{};
+    for (auto k : {1, 2, 7, 4, 10}) t5.insert_node(k);
+    CHECK_EQ(t5.size(), 5u);
+    CHECK_EQ(t5.root()->key, 2);
+    CHECK_EQ(black_height(t5.root()), 2);
+
+    std::array<int, 21> keys{3,  7,  10, 12, 14, 15, 16, 17, 19, 20, 29, 21, 23, 26, 28, 30, 35, 38, 39, 41, 47};
+    RbTree<IntNode> t21{};
+    for (auto k : keys) t21.insert_node(k);
+    CHECK_EQ(t21.size(), keys.size());
+    CHECK_EQ(t21.root()->key, 17);
+    int counter = 42;
+    auto perm = keys;
+    do {
+      RbTree<IntNode> tp{};
+      for (auto k : perm) tp.insert_node(k);
+      CHECK_EQ(tp.size(), perm.size());
+      black_height(tp.root());
+    } while (std::next_permutation(perm.begin(), perm.end()) && --counter > 0);
+
+    std::mt19937 gen(12345);
+    std::uniform_int_distribution<> dis(1, 100000);
+    for (int rep = 0; rep < 10; ++rep) {
+      std::vector<int> rk(5000);
+      std::generate(rk.begin(), rk.end(), [&] { return dis(gen); });
+      RbTree<IntNode> tr{};
+      tr.insert_node(rk);  // range overload
+      CHECK_EQ(tr.size(), rk.size());
+      black_height(tr.root());
+      // delete the root until empty (test_rb_tree.cpp:258-283)
+      for (std::size_t i = 0; i < rk.size(); ++i) {
+        tr.delete_node(tr.root());
+        if (i % 512 == 0) black_height(tr.root());
+      }
+      CHECK(tr.empty());
+    }
+
+    // delete (test_rb_tree.cpp:210-256, 285-299)
+    RbTree<IntNode> td{};
+    for (auto k : {1, 2, 4}) td.insert_node(k);
+    auto &left_child = td.root()->left;
+    td.delete_node(left_child);
+    CHECK_EQ(td.size(), 2u);
+    RbTree<IntNode> te{};
+    te.insert_node(keys);
+    te.delete_node(te.root());
+    te.delete_node(te.root());
+    CHECK_EQ(te.size(), 19u);
+    black_height(te.root());
+    for (int i = 0; i < 19; ++i) te.delete_node(te.root());
+    CHECK(te.empty());
+    std::array<int, 20> k1{54942, 75803, 49212, 64167, 14933, 44543, 10072, 90303, 45511, 70641,
+                           59710, 3100,  98544, 55068, 45575, 4994,  66267, 24721, 17128, 72975};
+    RbTree<IntNode> tk{};
+    tk.insert_node(k1);
+    CHECK_EQ(tk.size(), 20u);
+    CHECK_EQ(tk.search(54942)->key, 54942);
+    CHECK(tk.search(1) == nullptr);
+    tk.to_dot("rb_tree.dot");
+    CHECK(std::filesystem::exists("rb_tree.dot"));
+    std::filesystem::remove("rb_tree.dot");
+    for (std::size_t i = 0; i < k1.size(); ++i) tk.delete_node(tk.root());
+    CHECK(tk.empty());
+  }
+}
+
+static void gpu_cases() {
+  {  // single insert (test_interval_tree.cpp:74-85)
+    IntervalTree<UIntIntervalNode> t{};
+    t.insert_node(16u, 21u);
+    CHECK_EQ(t.size(), 1u);
+    IntervalTree<IntIntervalNode> ti{};
+    ti.insert_node(16, 21);
+    CHECK_EQ(ti.size(), 1u);
+    CHECK_EQ(ti.find_overlaps(-5, 16).size(), 1u);
+    CHECK_EQ(ti.find_overlaps(-5, 15).size(), 0u);
+  }
+  {  // insert multiple nodes (:87-99)
+    IntervalTree<UIntIntervalNode> t{};
+    t.insert_node(kFixture);
+    CHECK_EQ(t.size(), kFixture.size());
+    CHECK_EQ(t.root()->key, 16u);
+    black_height(t.root());
+    CHECK_EQ(t.root()->max, 30u);
+    CHECK_EQ(t.size(t.root()), 10u);
+    CHECK_EQ(t.minimum(t.root())->key, 0u);
+    CHECK_EQ(t.maximum(t.root())->key, 26u);
+  }
+  {  // 500 sequential inserts (:101-109)
+    IntervalTree<IntIntervalNode> t{};
+    for (int i = 0; i < 1000; i += 2) t.insert_node(i, i + 3);
+    CHECK_EQ(t.size(), 500u);
+    black_height(t.root());
+    CHECK_EQ(t.find_overlaps(10, 10).size(), 2u);  // [8,11] and [10,13]
+  }
+  {  // find overlap(s) (:111-144)
+    IntervalTree<UIntIntervalNode> t{};
+    t.insert_node(kFixture);
+    auto one = t.find_overlap(22u, 25u);
+    CHECK(one.has_value());
+    CHECK_EQ(one->low, 15u);
+    CHECK_EQ(one->high, 23u);
+    auto none = t.find_overlap(UIntInterval{100u, 111u});
+    CHECK(!none.has_value());
+    auto r1 = t.find_overlaps(UIntInterval{7u, 25u});
+    CHECK_EQ(r1.size(), 8u);
+    auto r2 = t.find_overlaps(15u, 25u);
+    CHECK_EQ(r2.size(), 5u);
+    // default order: insertion order
+    const std::vector<std::pair<unsigned, unsigned>> ins{{16, 21}, {15, 23}, {25, 30}, {17, 19}, {19, 20}};
+    for (std::size_t i = 0; i < r2.size(); ++i) CHECK(r2[i].low == ins[i].first && r2[i].high == ins[i].second);
+    // reference order on request ([16,21] [15,23] [19,20] [17,19] [25,30])
+    t.set_hit_order(HitOrder::ReferencePreorder);
+    auto r3 = t.find_overlaps(15u, 25u);
+    const std::vector<std::pair<unsigned, unsigned>> pre{{16, 21}, {15, 23}, {19, 20}, {17, 19}, {25, 30}};
+    CHECK_EQ(r3.size(), pre.size());
+    for (std::size_t i = 0; i < r3.size() && i < pre.size(); ++i)
+      CHECK(r3[i].low == pre[i].first && r3[i].high == pre[i].second);
+    auto r4 = t.find_overlaps(7u, 25u);
+    const std::vector<std::pair<unsigned, unsigned>> pre8{{16, 21}, {8, 9},   {5, 8},   {6, 10},
+                                                          {15, 23}, {19, 20}, {17, 19}, {25, 30}};
+    CHECK_EQ(r4.size(), pre8.size());
+    for (std::size_t i = 0; i < r4.size() && i < pre8.size(); ++i)
+      CHECK(r4[i].low == pre8[i].first && r4[i].high == pre8[i].second);
+    t.to_dot("interval_tree.dot");
+    CHECK(std::filesystem::exists("interval_tree.dot"));
+    std::filesystem::remove("interval_tree.dot");
+    // lvalue query (does not compile against the reference, :161; a superset is fine)
+    UIntInterval q{26u, 26u};
+    CHECK_EQ(t.find_overlaps(q).size(), 2u);
+  }
+  {  // same interval value (:146-155)
+    IntervalTree<UIntIntervalNode> t{};
+    for (int i = 0; i < 4; ++i) t.insert_node(1u, 4u);
+    CHECK_EQ(t.size(), 4u);
+    CHECK_EQ(t.find_overlaps(2u, 5u).size(), 4u);
+  }
+  {  // insert after a query, batch entry point, payload-carrying interval type
+    struct Tagged : UIntInterval {
+      using UIntInterval::UIntInterval;
+      Tagged() = default;
+      Tagged(std::uint32_t l, std::uint32_t h, int t) : UIntInterval(l, h), tag(t) {}
+      int tag{0};
+    };
+    IntervalTree<IntervalNode<Tagged>> t{};
+    t.insert_node(10u, 20u, 7);
+    CHECK_EQ(t.find_overlaps(15u, 15u).size(), 1u);
+    t.insert_node(12u, 13u, 9);
+    auto r = t.find_overlaps(13u, 18u);
+    CHECK_EQ(r.size(), 2u);
+    CHECK(r.size() == 2 && r[0].tag == 7 && r[1].tag == 9);
+    std::vector<Tagged> qs{Tagged{0u, 9u, 0}, Tagged{13u, 13u, 0}, Tagged{21u, 99u, 0}, Tagged{0u, 99u, 0}};
+    auto b = t.find_overlaps_batch(qs);
+    CHECK_EQ(b.offsets.size(), 5u);
+    CHECK(b.count(0) == 0 && b.count(1) == 2 && b.count(2) == 0 && b.count(3) == 2);
+    CHECK(b.hits(1)[0] == 0 && b.hits(1)[1] == 1);
+    CHECK_EQ(t.interval_at(1).tag, 9);
+  }
+  {  // empty tree
+    IntervalTree<UIntIntervalNode> t{};
+    CHECK(t.empty());
+    CHECK(!t.find_overlap(0u, 10u).has_value());
+    CHECK_EQ(t.find_overlaps(0u, 0xFFFFFFFFu).size(), 0u);
+    CHECK(t.root() == nullptr);
+  }
+}
+
+int main(int argc, char **argv) {
+  const bool no_gpu = argc > 1 && std::strcmp(argv[1], "--no-gpu") == 0;
+  try {
+    host_side_cases();
+    if (!no_gpu) gpu_cases();
+  } catch (const std::exception &e) {
+    std::printf("EXCEPTION: %s\n", e.what());
+    return 2;
+  }
+  std::printf("%d checks, %d failed\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}
