@@ -113,41 +113,55 @@ __device__ __forceinline__ uint32_t light_mask_pairs(const IndexView &v, uint32_
 // bit j <-> slot al + j, al = a rounded down to 2. If `keep` is given, the ids of the first kKeep hits are
 // written there (ascending slot order) as they are found; *nkept receives min(hits, kKeep).
 constexpr uint32_t kKeep = 4;
+
+// one chunk = 8 consecutive slots starting at the even slot c = al + c0, as four 16-byte loads
+__device__ __forceinline__ void packed_load_chunk(const IndexView &v, uint32_t c, uint32_t b, uint4 (&r)[4]) {
+  const uint4 *pairs = reinterpret_cast<const uint4 *>(v.rec);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t s = c + 2 * j;
+    if (s < b) r[j] = pairs[s >> 1];
+  }
+}
+
+// evaluates the predicate on a loaded chunk; returns the chunk's 8-bit hit mask (bit k <-> slot c + k)
+__device__ __forceinline__ uint32_t packed_eval_chunk(const Window &w, uint32_t sh, uint32_t lo, uint32_t hi,
+                                                      uint32_t c, const uint4 (&r)[4], uint32_t *keep, uint32_t &n) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t s = c + 2 * j;
+    if (s < w.b) {
+      const uint32_t rr[2] = {r[j].x, r[j].z}, ii[2] = {r[j].y, r[j].w};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint32_t i = s + e;
+        const uint32_t cell = (i >= w.t1 ? 1u : 0u) + (i >= w.t2 ? 1u : 0u);
+        const uint32_t low = w.cell0_low + (cell << sh) + (rr[e] & 0xFFFFu);
+        const uint32_t high = low + (rr[e] >> 16);
+        if (i >= w.a && i < w.b && low <= hi && high >= lo) {
+          m |= 1u << (2 * j + e);
+          if (keep) {
+            if (n < kKeep) keep[n] = ii[e];
+            ++n;
+          }
+        }
+      }
+    }
+  }
+  return m;
+}
+
 __device__ __forceinline__ uint32_t light_mask_packed(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
                                                       uint32_t hi, uint32_t &al, uint32_t *keep) {
-  const uint4 *pairs = reinterpret_cast<const uint4 *>(v.rec);
   al = w.a & ~1u;
   uint32_t mask = 0, n = 0;
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < kLight; c0 += 8) {
     if (al + c0 < w.b) {
       uint4 r[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t s = al + c0 + 2 * j;
-        if (s < w.b) r[j] = pairs[s >> 1];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t s = al + c0 + 2 * j;
-        if (s < w.b) {
-          const uint32_t rr[2] = {r[j].x, r[j].z}, ii[2] = {r[j].y, r[j].w};
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const uint32_t i = s + e;
-            const uint32_t cell = (i >= w.t1 ? 1u : 0u) + (i >= w.t2 ? 1u : 0u);
-            const uint32_t low = w.cell0_low + (cell << sh) + (rr[e] & 0xFFFFu);
-            const uint32_t high = low + (rr[e] >> 16);
-            if (i >= w.a && i < w.b && low <= hi && high >= lo) {
-              mask |= 1u << (c0 + 2 * j + e);
-              if (keep) {
-                if (n < kKeep) keep[n] = ii[e];
-                ++n;
-              }
-            }
-          }
-        }
-      }
+      packed_load_chunk(v, al + c0, w.b, r);
+      mask |= packed_eval_chunk(w, sh, lo, hi, al + c0, r, keep, n) << c0;
     }
   }
   return mask;
@@ -331,9 +345,9 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
 }
 
 // ---- single-pass kernel ----------------------------------------------------------------------------------
-// A workgroup owns kFTile = 1024 consecutive queries, four per thread. It counts them (remembering each short
-// window's hit mask), publishes its hit total, sums the totals of ALL earlier tiles, then writes offsets and
-// hit ids. One launch has at most kFMaxTiles tiles, so the prefix is a sweep over at most 1023 status words
+// A workgroup owns kFTile = 1024 consecutive queries. It counts them (remembering each short window's hit
+// mask and the ids of its first hits), publishes its hit total, sums the totals of ALL earlier tiles, then
+// writes offsets and hit ids. One launch has at most kFMaxTiles tiles, so the prefix is a sweep over at most 1023 status words
 // (16 loads per lane, issued four at a time) instead of a serial look-back chain: on MI355X every poll of
 // another XCD's status word goes to memory (per-XCD L2s are not coherent), so the number of dependent polls,
 // not their width, is what costs. Larger batches run as consecutive launches; each starts from the running
@@ -342,10 +356,10 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
 //   agent-scope atomic, so the value needs no separate fence. Tiles take tickets in launch order: every
 //   predecessor of a polling tile is already resident, the wait cannot deadlock; spins are bounded anyway.
 #ifndef BIVX_FUSED_THREADS
-#define BIVX_FUSED_THREADS 512
+#define BIVX_FUSED_THREADS 1024
 #endif
 #ifndef BIVX_FUSED_ROUNDS
-#define BIVX_FUSED_ROUNDS 2
+#define BIVX_FUSED_ROUNDS 1
 #endif
 constexpr int kFThreads = BIVX_FUSED_THREADS;
 constexpr int kFWaves = kFThreads / kWave;
@@ -361,6 +375,16 @@ __device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
 __device__ __forceinline__ void st_status(uint64_t *p, uint64_t w) {
   __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Diagnostic build only (-DBIVX_STAMPS): per-tile wall-clock stamps (100 MHz constant counter) written to a
+// buffer no other code reads; the product build has no stamp.
+#ifdef BIVX_STAMPS
+__device__ unsigned long long g_stamps[kFMaxTiles * 8];
+#define BIVX_STAMP(k) \
+  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kFMaxTiles) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define BIVX_STAMP(k)
+#endif
 
 template <bool LDS_DESC>
 __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
@@ -378,28 +402,36 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
+  BIVX_STAMP(0);
+#ifdef BIVX_NO_TICKET  // timing experiment only: relies on in-order dispatch, which HIP does not promise
+  if (threadIdx.x == 0) s_tile = blockIdx.x;
+#else
   if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<unsigned int *>(ws), 1u);
+#endif
   const SegDesc *segs;
   const uint32_t *cs;
   stage_descriptors<LDS_DESC>(v, s_seg, s_cs, segs, cs);
   __syncthreads();
   const uint32_t tile = s_tile;
   uint64_t *status = ws + 1;
+  BIVX_STAMP(1);
 
-  // phase 1: count the thread's four consecutive queries
+  // phase 1: count the thread's kFR consecutive queries
   const size_t q0 = q_begin + ((size_t)tile * kFThreads + threadIdx.x) * kFR;
   Query qy[kFR];
   Replay rp[kFR];
   uint32_t cnt[kFR];
   uint32_t tsum = 0;
 #pragma unroll
+  for (int r = 0; r < kFR; ++r) qy[r] = load_query(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
+#pragma unroll
   for (int r = 0; r < kFR; ++r) {
-    qy[r] = load_query(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
     cnt[r] = enumerate_hits<Mode::Count>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
                                          reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x]));
     tsum += cnt[r];
   }
 
+  BIVX_STAMP(2);
   // workgroup exclusive scan of the per-thread sums
   uint32_t incl = tsum;
 #pragma unroll
@@ -420,6 +452,7 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
 
   // prefix across tiles: wave 0 publishes this tile's total and sums every earlier tile's
   if (wave == 0) {
+    BIVX_STAMP(3);
     if (lane == 0) st_status(&status[tile], kStValid | (uint64_t)total);
     uint64_t sum = 0;
     for (uint32_t t0 = 0; t0 < tile; t0 += 4 * kWave) {
@@ -444,8 +477,10 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor((unsigned long long)sum, d, kWave);
     if (lane == 0) s_base = sum + (q_begin ? offsets[q_begin] : 0ull);
+    BIVX_STAMP(4);
   }
   __syncthreads();
+  BIVX_STAMP(5);
 
   // phase 2: offsets and hit ids. A query whose window was recorded replays its hit mask (ids only); the
   // others enumerate again with the lines of phase 1 still in this CU's L1 / this XCD's L2.
@@ -496,6 +531,10 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
     (void)enumerate_hits<Mode::Fill>(v, segs, qy[r], hits, pos, cap, nullptr);
     pos += cnt[r];
   }
+  BIVX_STAMP(6);
+#ifdef BIVX_STAMPS
+  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kFMaxTiles) * 8 + 7] = tile;
+#endif
 }
 
 // ---- per-query ascending-id ordering of a CSR hit list ------------------------------------------------
@@ -650,6 +689,13 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
   BIVX_HIP(hipGetLastError());
   return 0;
 }
+
+#ifdef BIVX_STAMPS
+extern "C" int bivx_debug_stamps(unsigned long long *out, size_t n) {
+  if (n > (size_t)kFMaxTiles * 8) n = (size_t)kFMaxTiles * 8;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, hipStream_t s) {
   if (q == 0) return 0;
