@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 --pmc passes of `python bench.py` into profiles/pmc_traffic.json: HBM-side bytes per
+launch of the dominant kernel (k_query_fused), per MI355X_MICROARCH.md §HBM:
+  read bytes  = TCC_EA0_RDREQ split by request size (32/64/128 B); FETCH_SIZE is shown beside it — on gfx950 it
+                tallies 128-B requests at 64 B, so it reads half of the request-derived figure
+  write bytes = WRITE_SIZE (KiB) cross-checked with TCC_EA0_WRREQ (64-B requests)
+usage: pmc_traffic.py <dir with the pmc passes> <out.json>"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+acc = defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_query_fused" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg = {k: sum(v) / len(v) for k, v in acc.items()}
+rd = avg.get("TCC_EA0_RDREQ_sum", 0.0)
+rd32, rd64 = avg.get("TCC_EA0_RDREQ_32B_sum", 0.0), avg.get("TCC_EA0_RDREQ_64B_sum", 0.0)
+rd128 = avg.get("TCC_EA0_RDREQ_128B_sum", rd - rd32 - rd64)
+read_bytes = rd32 * 32 + rd64 * 64 + rd128 * 128
+wr = avg.get("TCC_EA0_WRREQ_sum", 0.0)
+wr64 = avg.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+write_bytes_req = wr64 * 64 + (wr - wr64) * 32
+out = {
+    "kernel": "k_query_fused", "launches_sampled": len(acc.get("TCC_EA0_RDREQ_sum", [])),
+    "counters_avg_per_launch": avg,
+    "read_bytes_per_launch": read_bytes,
+    "fetch_size_bytes_per_launch_uncorrected": avg.get("FETCH_SIZE", 0.0) * 1024,
+    "fetch_size_bytes_per_launch_x2": avg.get("FETCH_SIZE", 0.0) * 2048,
+    "write_bytes_per_launch_from_requests": write_bytes_req,
+    "write_size_bytes_per_launch": avg.get("WRITE_SIZE", 0.0) * 1024,
+    "traffic_bytes_per_step": read_bytes + (avg.get("WRITE_SIZE", 0.0) * 1024 or write_bytes_req),
+    "method": "read = sum over TCC_EA0_RDREQ request sizes; write = WRITE_SIZE; separate --pmc passes, "
+              "averaged over the launches of the bench's timed loop",
+}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps({k: out[k] for k in out if k != "counters_avg_per_launch"}, indent=1))
