@@ -17,6 +17,7 @@ EXPORTS = (
     "bivx_append_dev", "bivx_clear", "bivx_build", "bivx_is_built", "bivx_size", "bivx_num_chroms",
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_workspace_bytes", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
+    "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f",
 )
 
 
@@ -24,6 +25,15 @@ class BivxError(RuntimeError):
     def __init__(self, code: int, text: str):
         super().__init__(f"libbivx error {code}: {text}")
         self.code = code
+
+
+FILTER_NONE, FILTER_SV2NL_DUP, FILTER_SV2NL_INV, FILTER_SV2NL_TRA = 0, 1, 2, 3
+
+
+class Filter(C.Structure):
+    """bivx_filter (include/bivx.h): fused sv2nl check_condition."""
+    _fields_ = [("kind", C.c_uint32), ("max_dist", C.c_uint32), ("use_strand", C.c_uint32), ("reserved", C.c_uint32),
+                ("query_aux", C.c_void_p), ("interval_aux", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -74,6 +84,12 @@ def load() -> C.CDLL:
     L.bivx_any.argtypes = [vp, u32p, u32p, u32p, sz, u32p]
     L.bivx_any_dev.argtypes = [vp, u32p, u32p, u32p, sz, u32p, vp]
     L.bivx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    fp = C.POINTER(Filter)
+    L.bivx_count_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p]
+    L.bivx_fill_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, C.c_int]
+    L.bivx_count_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, vp, sz, vp]
+    L.bivx_fill_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, vp]
+    L.bivx_query_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, C.c_uint64, vp, sz, vp]
     if L.bivx_abi_version() >> 16 != ABI_VERSION >> 16:
         raise ImportError("libbivx.so ABI major version mismatch")
     _lib = L

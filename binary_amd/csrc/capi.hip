@@ -269,7 +269,36 @@ IndexView view_of(const bivx_index *idx) {
   v.chrom_seg = idx->d_chrom_seg;
   v.nchrom = idx->nchrom;
   v.nseg = idx->nseg;
+  v.flt_kind = BIVX_FILTER_NONE;
+  v.flt_dist = 0;
+  v.flt_strand = 0;
+  v.flt_qaux = nullptr;
+  v.flt_iaux = nullptr;
   return v;
+}
+
+// view with a fused post-filter; the aux pointers are DEVICE pointers here
+int view_with_filter(const bivx_index *idx, const bivx_filter *f, IndexView &v) {
+  v = view_of(idx);
+  if (!f || f->kind == BIVX_FILTER_NONE) return 0;
+  if (f->kind > BIVX_FILTER_SV2NL_TRA) {
+    set_error("unknown filter kind %u", f->kind);
+    return BIVX_E_INVALID;
+  }
+  if (f->kind == BIVX_FILTER_SV2NL_TRA && (!f->query_aux || !f->interval_aux)) {
+    set_error("BIVX_FILTER_SV2NL_TRA needs query_aux and interval_aux");
+    return BIVX_E_INVALID;
+  }
+  if (f->kind == BIVX_FILTER_SV2NL_INV && f->use_strand && !f->query_aux) {
+    set_error("BIVX_FILTER_SV2NL_INV with use_strand needs query_aux");
+    return BIVX_E_INVALID;
+  }
+  v.flt_kind = f->kind;
+  v.flt_dist = f->max_dist;
+  v.flt_strand = f->use_strand;
+  v.flt_qaux = f->query_aux;
+  v.flt_iaux = f->interval_aux;
+  return 0;
 }
 
 int check_query_args(const bivx_index *idx, const void *qlow, const void *qhigh, size_t q, const char *who) {
@@ -491,7 +520,15 @@ size_t bivx_count_workspace_bytes(size_t q) { return align_up((q ? q : 1) * 4, 2
 
 int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                    size_t q, uint64_t *d_offsets, void *d_workspace, size_t workspace_bytes, void *stream) {
+  return bivx_count_dev_f(idx, d_qchrom, d_qlow, d_qhigh, q, nullptr, d_offsets, d_workspace, workspace_bytes, stream);
+}
+
+int bivx_count_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                     size_t q, const bivx_filter *filter, uint64_t *d_offsets, void *d_workspace,
+                     size_t workspace_bytes, void *stream) {
   BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_count_dev"));
+  IndexView view;
+  BIVX_TRY(view_with_filter(idx, filter, view));
   if (!d_offsets) {
     set_error("bivx_count_dev: null d_offsets");
     return BIVX_E_INVALID;
@@ -510,7 +547,7 @@ int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32
   }
   uint32_t *d_counts = static_cast<uint32_t *>(ws);
   void *scan_scr = static_cast<uint8_t *>(ws) + align_up((q ? q : 1) * 4, 256);
-  int rc = launch_count(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_counts, s);
+  int rc = launch_count(view, d_qchrom, d_qlow, d_qhigh, q, d_counts, s);
   if (rc == 0) rc = exclusive_scan_u32_u64(d_counts, d_offsets, q, scan_scr, s);
   if (own) (void)hipFreeAsync(ws, s);
   return rc;
@@ -518,13 +555,20 @@ int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32
 
 int bivx_fill_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                   size_t q, const uint64_t *d_offsets, uint32_t *d_hit_ids, void *stream) {
+  return bivx_fill_dev_f(idx, d_qchrom, d_qlow, d_qhigh, q, nullptr, d_offsets, d_hit_ids, stream);
+}
+
+int bivx_fill_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                    size_t q, const bivx_filter *filter, const uint64_t *d_offsets, uint32_t *d_hit_ids, void *stream) {
   BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_fill_dev"));
+  IndexView view;
+  BIVX_TRY(view_with_filter(idx, filter, view));
   if (q && !d_offsets) {
     set_error("bivx_fill_dev: null d_offsets");
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
-  return launch_fill(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, static_cast<hipStream_t>(stream));
+  return launch_fill(view, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, static_cast<hipStream_t>(stream));
 }
 
 size_t bivx_query_workspace_bytes(size_t q) { return fused_workspace_bytes(q); }
@@ -532,7 +576,16 @@ size_t bivx_query_workspace_bytes(size_t q) { return fused_workspace_bytes(q); }
 int bivx_query_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                    size_t q, uint64_t *d_offsets, uint32_t *d_hit_ids, uint64_t hit_capacity, void *d_workspace,
                    size_t workspace_bytes, void *stream) {
+  return bivx_query_dev_f(idx, d_qchrom, d_qlow, d_qhigh, q, nullptr, d_offsets, d_hit_ids, hit_capacity, d_workspace,
+                          workspace_bytes, stream);
+}
+
+int bivx_query_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                     size_t q, const bivx_filter *filter, uint64_t *d_offsets, uint32_t *d_hit_ids,
+                     uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes, void *stream) {
   BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_query_dev"));
+  IndexView view;
+  BIVX_TRY(view_with_filter(idx, filter, view));
   if (!d_offsets || (hit_capacity && !d_hit_ids) || !d_workspace) {
     set_error("bivx_query_dev: null argument");
     return BIVX_E_INVALID;
@@ -542,7 +595,7 @@ int bivx_query_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
-  return launch_query_fused(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, hit_capacity,
+  return launch_query_fused(view, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, hit_capacity,
                             d_workspace, static_cast<hipStream_t>(stream));
 }
 
@@ -586,8 +639,36 @@ int upload_queries(TempPool &tmp, const uint32_t *qchrom, const uint32_t *qlow, 
 }
 }  // namespace
 
+namespace {
+// uploads a host-side filter's aux arrays; `dev` receives the same filter with device pointers
+int upload_filter(TempPool &tmp, const bivx_index *idx, const bivx_filter *f, size_t q, hipStream_t s, bivx_filter &dev) {
+  dev = bivx_filter{};
+  if (!f || f->kind == BIVX_FILTER_NONE) return 0;
+  dev = *f;
+  dev.query_aux = dev.interval_aux = nullptr;
+  if (f->query_aux && q) {
+    uint32_t *d = nullptr;
+    BIVX_TRY(tmp.alloc(&d, q));
+    BIVX_HIP(hipMemcpyAsync(d, f->query_aux, q * 4, hipMemcpyHostToDevice, s));
+    dev.query_aux = d;
+  }
+  if (f->interval_aux && idx->n) {
+    uint32_t *d = nullptr;
+    BIVX_TRY(tmp.alloc(&d, idx->n));
+    BIVX_HIP(hipMemcpyAsync(d, f->interval_aux, idx->n * 4, hipMemcpyHostToDevice, s));
+    dev.interval_aux = d;
+  }
+  return 0;
+}
+}  // namespace
+
 int bivx_count(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
                uint64_t *offsets_out) {
+  return bivx_count_f(idx, qchrom, qlow, qhigh, q, nullptr, offsets_out);
+}
+
+int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
+                 const bivx_filter *filter, uint64_t *offsets_out) {
   BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_count"));
   if (!offsets_out) {
     set_error("bivx_count: null offsets_out");
@@ -607,7 +688,9 @@ int bivx_count(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *ql
   const size_t wsb = bivx_count_workspace_bytes(q);
   BIVX_TRY(tmp.alloc(&d_off, q + 1));
   BIVX_TRY(tmp.alloc(&d_ws, wsb));
-  BIVX_TRY(bivx_count_dev(idx, d.c, d.lo, d.hi, q, d_off, d_ws, wsb, s));
+  bivx_filter dflt;
+  BIVX_TRY(upload_filter(tmp, idx, filter, q, s, dflt));
+  BIVX_TRY(bivx_count_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, d_ws, wsb, s));
   BIVX_HIP(hipMemcpyAsync(offsets_out, d_off, (q + 1) * 8, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
   return 0;
@@ -615,6 +698,11 @@ int bivx_count(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *ql
 
 int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
               const uint64_t *offsets, uint32_t *hit_ids_out, int sort_by_id) {
+  return bivx_fill_f(idx, qchrom, qlow, qhigh, q, nullptr, offsets, hit_ids_out, sort_by_id);
+}
+
+int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
+                const bivx_filter *filter, const uint64_t *offsets, uint32_t *hit_ids_out, int sort_by_id) {
   BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_fill"));
   if (q == 0) return 0;
   if (!offsets) {
@@ -636,7 +724,9 @@ int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlo
   BIVX_TRY(tmp.alloc(&d_off, q + 1));
   BIVX_TRY(tmp.alloc(&d_hits, (size_t)total));
   BIVX_HIP(hipMemcpyAsync(d_off, offsets, (q + 1) * 8, hipMemcpyHostToDevice, s));
-  BIVX_TRY(bivx_fill_dev(idx, d.c, d.lo, d.hi, q, d_off, d_hits, s));
+  bivx_filter dflt;
+  BIVX_TRY(upload_filter(tmp, idx, filter, q, s, dflt));
+  BIVX_TRY(bivx_fill_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, d_hits, s));
   if (sort_by_id) BIVX_TRY(bivx_sort_hits_dev(idx, d_off, d_hits, q, s));
   if (total) BIVX_HIP(hipMemcpyAsync(hit_ids_out, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));

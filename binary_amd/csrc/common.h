@@ -55,6 +55,12 @@ struct IndexView {
   const uint32_t *chrom_seg;  // nchrom + 1: segments of chromosome c are [chrom_seg[c], chrom_seg[c+1])
   uint32_t nchrom;
   uint32_t nseg;
+  // optional post-filter fused into the enumeration (bivx_filter): a candidate must pass it as well
+  uint32_t flt_kind;          // BIVX_FILTER_*
+  uint32_t flt_dist;
+  uint32_t flt_strand;
+  const uint32_t *flt_qaux;   // per query
+  const uint32_t *flt_iaux;   // per interval, append order
 };
 
 // per (chromosome, length bin) statistics gathered before the sort

@@ -79,9 +79,38 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t x) {
   return x;
 }
 
+// ---- fused post-filters (include/bivx.h, bivx_filter) -----------------------------------------------------------
+// sv2nl's per-mapper check_condition, applied to a candidate that already overlaps the query; (lo, hi) is the
+// validated NL record, (low, high) the SV record as stored in the tree (reference standalone/sv2nl/):
+//   DUP  source/mapper.cpp:50-55   is_contained(sv, nl) && distance_less(nl, sv, d)        (helper.hpp:16-40)
+//   INV  source/mapper.cpp:57-79   neither contains the other, within d, then the strand side rule
+//   TRA  source/mapper.cpp:144-156 same ordered chromosome pair and both breakpoints within d (helper.hpp:76-82)
+__device__ __forceinline__ uint32_t absdiff(uint32_t a, uint32_t b) { return a >= b ? a - b : b - a; }
+
+__device__ __forceinline__ bool filter_accept(const IndexView &v, uint32_t lo, uint32_t hi, uint32_t qaux, uint32_t low,
+                                              uint32_t high, uint32_t id) {
+  const uint32_t d = v.flt_dist;
+  if (v.flt_kind == BIVX_FILTER_SV2NL_TRA) {
+    const uint32_t ia = v.flt_iaux[id];
+    if ((ia >> 1) != (qaux >> 1)) return false;
+    const uint32_t q1 = (qaux & 1u) ? hi : lo, q2 = (qaux & 1u) ? lo : hi;
+    const uint32_t i1 = (ia & 1u) ? high : low, i2 = (ia & 1u) ? low : high;
+    return absdiff(q1, i1) <= d && absdiff(q2, i2) <= d;
+  }
+  const bool sv_has_nl = low <= lo && high >= hi;
+  const bool near = absdiff(lo, low) <= d && absdiff(hi, high) <= d;
+  if (v.flt_kind == BIVX_FILTER_SV2NL_DUP) return sv_has_nl && near;
+  // INV
+  const bool nl_has_sv = lo <= low && hi >= high;
+  if (sv_has_nl || nl_has_sv || !near) return false;
+  if (!v.flt_strand) return true;
+  const bool s1 = (qaux & 1u) != 0, s2 = (qaux & 2u) != 0;
+  return lo <= low ? (s1 && !s2) : (!s1 && s2);
+}
+
 // hit mask of a short window over 8-byte (low, high) pairs; bit j <-> slot al + j, al = a rounded down to 2
 __device__ __forceinline__ uint32_t light_mask_pairs(const IndexView &v, uint32_t a, uint32_t b, uint32_t lo,
-                                                     uint32_t hi, uint32_t &al) {
+                                                     uint32_t hi, uint32_t qaux, uint32_t &al) {
   const uint4 *pairs = reinterpret_cast<const uint4 *>(v.se);
   al = a & ~1u;
   uint32_t mask = 0;
@@ -98,8 +127,12 @@ __device__ __forceinline__ uint32_t light_mask_pairs(const IndexView &v, uint32_
       for (int j = 0; j < 4; ++j) {
         const uint32_t s = al + c0 + 2 * j;
         if (s < b) {
-          if (s >= a && r[j].x <= hi && r[j].y >= lo) mask |= 1u << (c0 + 2 * j);
-          if (s + 1 < b && r[j].z <= hi && r[j].w >= lo) mask |= 1u << (c0 + 2 * j + 1);
+          if (s >= a && r[j].x <= hi && r[j].y >= lo &&
+              (v.flt_kind == BIVX_FILTER_NONE || filter_accept(v, lo, hi, qaux, r[j].x, r[j].y, v.id[s])))
+            mask |= 1u << (c0 + 2 * j);
+          if (s + 1 < b && r[j].z <= hi && r[j].w >= lo &&
+              (v.flt_kind == BIVX_FILTER_NONE || filter_accept(v, lo, hi, qaux, r[j].z, r[j].w, v.id[s + 1])))
+            mask |= 1u << (c0 + 2 * j + 1);
         }
       }
     }
@@ -125,8 +158,9 @@ __device__ __forceinline__ void packed_load_chunk(const IndexView &v, uint32_t c
 }
 
 // evaluates the predicate on a loaded chunk; returns the chunk's 8-bit hit mask (bit k <-> slot c + k)
-__device__ __forceinline__ uint32_t packed_eval_chunk(const Window &w, uint32_t sh, uint32_t lo, uint32_t hi,
-                                                      uint32_t c, const uint4 (&r)[4], uint32_t *keep, uint32_t &n) {
+__device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
+                                                      uint32_t hi, uint32_t qaux, uint32_t c, const uint4 (&r)[4],
+                                                      uint32_t *keep, uint32_t &n) {
   uint32_t m = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -139,7 +173,8 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const Window &w, uint32_t 
         const uint32_t cell = (i >= w.t1 ? 1u : 0u) + (i >= w.t2 ? 1u : 0u);
         const uint32_t low = w.cell0_low + (cell << sh) + (rr[e] & 0xFFFFu);
         const uint32_t high = low + (rr[e] >> 16);
-        if (i >= w.a && i < w.b && low <= hi && high >= lo) {
+        if (i >= w.a && i < w.b && low <= hi && high >= lo &&
+            (v.flt_kind == BIVX_FILTER_NONE || filter_accept(v, lo, hi, qaux, low, high, ii[e]))) {
           m |= 1u << (2 * j + e);
           if (keep) {
             if (n < kKeep) keep[n] = ii[e];
@@ -153,7 +188,7 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const Window &w, uint32_t 
 }
 
 __device__ __forceinline__ uint32_t light_mask_packed(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
-                                                      uint32_t hi, uint32_t &al, uint32_t *keep) {
+                                                      uint32_t hi, uint32_t qaux, uint32_t &al, uint32_t *keep) {
   al = w.a & ~1u;
   uint32_t mask = 0, n = 0;
 #pragma unroll 1
@@ -161,7 +196,7 @@ __device__ __forceinline__ uint32_t light_mask_packed(const IndexView &v, const 
     if (al + c0 < w.b) {
       uint4 r[4];
       packed_load_chunk(v, al + c0, w.b, r);
-      mask |= packed_eval_chunk(w, sh, lo, hi, al + c0, r, keep, n) << c0;
+      mask |= packed_eval_chunk(v, w, sh, lo, hi, qaux, al + c0, r, keep, n) << c0;
     }
   }
   return mask;
@@ -173,6 +208,7 @@ enum class Mode { Count, Fill, Any };
 struct Query {
   uint32_t lo, hi;
   uint32_t s0, nseg;  // segments [s0, s0 + nseg) of the query's chromosome
+  uint32_t aux;       // per-query word of the fused post-filter (0 without a filter)
 };
 
 // What a lane remembers from a counting pass so that the fill needs no second look at the intervals:
@@ -218,10 +254,10 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       uint32_t mask;
       if (packed) {
         const bool want = M == Mode::Count && keep != nullptr && qy.nseg == 1;
-        mask = light_mask_packed(v, w, shf & 31u, lo, hi, al, want ? keep : nullptr);
+        mask = light_mask_packed(v, w, shf & 31u, lo, hi, qy.aux, al, want ? keep : nullptr);
         if (M == Mode::Count && rp) rp->kept = want;
       } else {
-        mask = light_mask_pairs(v, w.a, w.b, lo, hi, al);
+        mask = light_mask_pairs(v, w.a, w.b, lo, hi, qy.aux, al);
       }
       if (M == Mode::Count) {
         acc += (uint32_t)__popc(mask);
@@ -249,20 +285,21 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       hm &= hm - 1;
       const uint32_t ca = __shfl(w.a, src, kWave), cb = __shfl(w.b, src, kWave);
       const uint32_t cl = __shfl(lo, src, kWave), ch = __shfl(hi, src, kWave);
+      const uint32_t cx = __shfl(qy.aux, src, kWave);
+      auto is_hit = [&](uint32_t j) {
+        const uint2 e = v.se[j];
+        return e.x <= ch && e.y >= cl &&
+               (v.flt_kind == BIVX_FILTER_NONE || filter_accept(v, cl, ch, cx, e.x, e.y, v.id[j]));
+      };
       if (M == Mode::Count) {
         uint32_t c = 0;
-        for (uint32_t j = ca + lane; j < cb; j += kWave) {
-          const uint2 e = v.se[j];
-          c += (e.x <= ch && e.y >= cl) ? 1u : 0u;
-        }
+        for (uint32_t j = ca + lane; j < cb; j += kWave) c += is_hit(j) ? 1u : 0u;
         c = wave_sum(c);
         if (lane == src) acc += c;
       } else if (M == Mode::Any) {
         uint32_t m = BIVX_NO_HIT;
-        for (uint32_t j = ca + lane; j < cb; j += kWave) {
-          const uint2 e = v.se[j];
-          if (e.x <= ch && e.y >= cl) m = min(m, v.id[j]);
-        }
+        for (uint32_t j = ca + lane; j < cb; j += kWave)
+          if (is_hit(j)) m = min(m, v.id[j]);
         m = wave_min(m);
         if (lane == src) acc = min(acc, m);
       } else {
@@ -271,11 +308,7 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
         uint32_t written = 0;
         for (uint32_t j0 = ca; j0 < cb; j0 += kWave) {
           const uint32_t j = j0 + lane;
-          bool hit = false;
-          if (j < cb) {
-            const uint2 e = v.se[j];
-            hit = e.x <= ch && e.y >= cl;
-          }
+          const bool hit = j < cb && is_hit(j);
           const uint64_t m = __ballot(hit);
           if (hit) {
             const uint64_t p = pos0 + written + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -309,10 +342,11 @@ __device__ __forceinline__ void stage_descriptors(const IndexView &v, SegDesc *s
 
 __device__ __forceinline__ Query load_query(const IndexView &v, const uint32_t *cs, const uint32_t *qchrom,
                                             const uint32_t *qlow, const uint32_t *qhigh, size_t q, bool valid) {
-  Query qy{0u, 0u, 0u, 0u};
+  Query qy{0u, 0u, 0u, 0u, 0u};
   if (valid) {
     qy.lo = qlow[q];
     qy.hi = qhigh[q];
+    if (v.flt_qaux) qy.aux = v.flt_qaux[q];
     const uint32_t c = qchrom ? qchrom[q] : 0u;
     if (c < v.nchrom) {
       qy.s0 = cs[c];

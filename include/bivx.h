@@ -132,6 +132,47 @@ int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow
 int bivx_any_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                  const uint32_t *d_qhigh, size_t q, uint32_t *d_first_id, void *stream);
 
+/* ---- fused post-filters ---------------------------------------------------------------------------
+ * replaces: the check_condition step that sv2nl applies to every find_overlaps hit
+ * (standalone/sv2nl/include/mapper.hpp:219-223; DupMapper / InvMapper / TraMapper::check_condition,
+ * source/mapper.cpp:50-79,144-156; predicates include/helper.hpp:16-46,76-82). A candidate that overlaps the
+ * query must ALSO pass the filter to be counted / reported, so only surviving pairs are ever written.
+ * Operands: the query interval is the validated NL record (pos, svend), the stored interval the SV record as
+ * inserted. Everything is unsigned-safe |a - b| arithmetic on uint32, as in the reference.
+ *   BIVX_FILTER_SV2NL_DUP  low <= q.low && high >= q.high && |q.low-low| <= d && |q.high-high| <= d
+ *   BIVX_FILTER_SV2NL_INV  neither interval contains the other && both distances <= d && (use_strand == 0 ||
+ *                          (q.low <= low ? s1 && !s2 : !s1 && s2)); query_aux bit0 = STRAND1 is '+', bit1 = STRAND2
+ *   BIVX_FILTER_SV2NL_TRA  aux = pair_id << 1 | swapped, on both sides (pair_id: id of the record's ordered
+ *                          chromosome pair; swapped: chrom > chr2, i.e. breakpoint 1 is `high`): equal pair_id
+ *                          and |bp1 - bp1'| <= d and |bp2 - bp2'| <= d
+ * query_aux has one word per query, interval_aux one word per interval in append order; host pointers for the
+ * host entry points, device pointers for the _dev ones; either may be NULL when the kind does not read it. */
+enum { BIVX_FILTER_NONE = 0, BIVX_FILTER_SV2NL_DUP = 1, BIVX_FILTER_SV2NL_INV = 2, BIVX_FILTER_SV2NL_TRA = 3 };
+typedef struct bivx_filter {
+  uint32_t kind;
+  uint32_t max_dist;   /* sv2nl --dis */
+  uint32_t use_strand; /* sv2nl: !--short */
+  uint32_t reserved;
+  const uint32_t *query_aux;
+  const uint32_t *interval_aux;
+} bivx_filter;
+
+/* the filtered forms of count / fill / query; filter == NULL or kind == BIVX_FILTER_NONE gives the plain calls */
+int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                 size_t q, const bivx_filter *filter, uint64_t *offsets_out);
+int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                size_t q, const bivx_filter *filter, const uint64_t *offsets, uint32_t *hit_ids_out, int sort_by_id);
+int bivx_count_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                     const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, uint64_t *d_offsets,
+                     void *d_workspace, size_t workspace_bytes, void *stream);
+int bivx_fill_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                    const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, const uint64_t *d_offsets,
+                    uint32_t *d_hit_ids, void *stream);
+int bivx_query_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                     const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, uint64_t *d_offsets,
+                     uint32_t *d_hit_ids, uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes,
+                     void *stream);
+
 /* ---- introspection (bench / DESIGN.md numbers) -------------------------------------------------- */
 typedef struct bivx_stats {
   uint64_t n_intervals;
