@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -46,6 +48,10 @@ struct bivx_index {
   uint64_t nentries = 0;
   size_t built_n = 0;
   double build_ms = 0.0;
+  // prefix workspaces of bivx_query_dev calls made without a caller workspace: one per stream (calls on one
+  // stream are ordered, so they can share it); zeroed once, and every launch leaves its workspace zeroed again
+  mutable std::mutex ws_mutex;
+  mutable std::unordered_map<hipStream_t, void *> ws_of_stream;
 };
 
 namespace {
@@ -357,6 +363,8 @@ void bivx_destroy(bivx_index *idx) {
   if (!idx) return;
   DeviceGuard g(idx->device);
   if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+  (void)hipDeviceSynchronize();
+  for (auto &kv : idx->ws_of_stream) (void)hipFree(kv.second);
   free_built(idx);
   (void)hipFree(idx->d_chrom);
   (void)hipFree(idx->d_low);
@@ -399,6 +407,10 @@ int bivx_build(bivx_index *idx) {
   hipStream_t s = idx->stream;
   // appends made with bivx_append_dev on a caller stream must be complete before we read them
   BIVX_HIP(hipDeviceSynchronize());
+  {
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    for (auto &kv : idx->ws_of_stream) BIVX_HIP(hipMemset(kv.second, 0, fused_workspace_bytes(0)));
+  }
   free_built(idx);
   const size_t n = idx->n;
   TempPool tmp;
@@ -586,17 +598,31 @@ int bivx_query_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint
   BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_query_dev"));
   IndexView view;
   BIVX_TRY(view_with_filter(idx, filter, view));
-  if (!d_offsets || (hit_capacity && !d_hit_ids) || !d_workspace) {
+  if (!d_offsets || (hit_capacity && !d_hit_ids)) {
     set_error("bivx_query_dev: null argument");
     return BIVX_E_INVALID;
   }
-  if (workspace_bytes < fused_workspace_bytes(q)) {
+  if (d_workspace && workspace_bytes < fused_workspace_bytes(q)) {
     set_error("bivx_query_dev: workspace too small (%zu < %zu)", workspace_bytes, fused_workspace_bytes(q));
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
-  return launch_query_fused(view, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, hit_capacity,
-                            d_workspace, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bool self_clean = false;
+  if (!d_workspace) {  // the index's own per-stream workspace: no memset in front of the kernel
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    auto it = idx->ws_of_stream.find(s);
+    if (it == idx->ws_of_stream.end()) {
+      void *p = nullptr;
+      BIVX_HIP(hipMalloc(&p, fused_workspace_bytes(q)));
+      BIVX_HIP(hipMemset(p, 0, fused_workspace_bytes(q)));
+      it = idx->ws_of_stream.emplace(s, p).first;
+    }
+    d_workspace = it->second;
+    self_clean = true;
+  }
+  return launch_query_fused(view, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, hit_capacity, d_workspace,
+                            self_clean, s);
 }
 
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q, void *stream) {

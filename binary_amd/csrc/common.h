@@ -112,6 +112,6 @@ int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, hipS
 size_t fused_workspace_bytes(size_t q);
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
-                       void *d_ws, hipStream_t s);
+                       void *d_ws, bool self_clean, hipStream_t s);
 
 }  // namespace bivx

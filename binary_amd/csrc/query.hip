@@ -109,6 +109,7 @@ __device__ __forceinline__ bool filter_accept(const IndexView &v, uint32_t lo, u
 }
 
 // hit mask of a short window over 8-byte (low, high) pairs; bit j <-> slot al + j, al = a rounded down to 2
+template <bool F>
 __device__ __forceinline__ uint32_t light_mask_pairs(const IndexView &v, uint32_t a, uint32_t b, uint32_t lo,
                                                      uint32_t hi, uint32_t qaux, uint32_t &al) {
   const uint4 *pairs = reinterpret_cast<const uint4 *>(v.se);
@@ -128,10 +129,10 @@ __device__ __forceinline__ uint32_t light_mask_pairs(const IndexView &v, uint32_
         const uint32_t s = al + c0 + 2 * j;
         if (s < b) {
           if (s >= a && r[j].x <= hi && r[j].y >= lo &&
-              (v.flt_kind == BIVX_FILTER_NONE || filter_accept(v, lo, hi, qaux, r[j].x, r[j].y, v.id[s])))
+              (!F || filter_accept(v, lo, hi, qaux, r[j].x, r[j].y, v.id[s])))
             mask |= 1u << (c0 + 2 * j);
           if (s + 1 < b && r[j].z <= hi && r[j].w >= lo &&
-              (v.flt_kind == BIVX_FILTER_NONE || filter_accept(v, lo, hi, qaux, r[j].z, r[j].w, v.id[s + 1])))
+              (!F || filter_accept(v, lo, hi, qaux, r[j].z, r[j].w, v.id[s + 1])))
             mask |= 1u << (c0 + 2 * j + 1);
         }
       }
@@ -158,6 +159,7 @@ __device__ __forceinline__ void packed_load_chunk(const IndexView &v, uint32_t c
 }
 
 // evaluates the predicate on a loaded chunk; returns the chunk's 8-bit hit mask (bit k <-> slot c + k)
+template <bool F>
 __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
                                                       uint32_t hi, uint32_t qaux, uint32_t c, const uint4 (&r)[4],
                                                       uint32_t *keep, uint32_t &n) {
@@ -174,7 +176,7 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const 
         const uint32_t low = w.cell0_low + (cell << sh) + (rr[e] & 0xFFFFu);
         const uint32_t high = low + (rr[e] >> 16);
         if (i >= w.a && i < w.b && low <= hi && high >= lo &&
-            (v.flt_kind == BIVX_FILTER_NONE || filter_accept(v, lo, hi, qaux, low, high, ii[e]))) {
+            (!F || filter_accept(v, lo, hi, qaux, low, high, ii[e]))) {
           m |= 1u << (2 * j + e);
           if (keep) {
             if (n < kKeep) keep[n] = ii[e];
@@ -187,6 +189,7 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const 
   return m;
 }
 
+template <bool F>
 __device__ __forceinline__ uint32_t light_mask_packed(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
                                                       uint32_t hi, uint32_t qaux, uint32_t &al, uint32_t *keep) {
   al = w.a & ~1u;
@@ -196,7 +199,7 @@ __device__ __forceinline__ uint32_t light_mask_packed(const IndexView &v, const 
     if (al + c0 < w.b) {
       uint4 r[4];
       packed_load_chunk(v, al + c0, w.b, r);
-      mask |= packed_eval_chunk(v, w, sh, lo, hi, qaux, al + c0, r, keep, n) << c0;
+      mask |= packed_eval_chunk<F>(v, w, sh, lo, hi, qaux, al + c0, r, keep, n) << c0;
     }
   }
   return mask;
@@ -224,7 +227,7 @@ struct Replay {
 //   Count: returns the number of hits (and fills *rp).   Any: returns the smallest hit id (BIVX_NO_HIT if none).
 //   Fill:  writes hit ids to hits_base[dst_pos ..), in index order, only positions below `cap`;
 //          returns the number of hits.
-template <Mode M>
+template <Mode M, bool F>
 __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const SegDesc *segs, const Query &qy,
                                                    uint32_t *hits_base, uint64_t dst_pos, uint64_t cap,
                                                    Replay *rp, uint32_t *keep = nullptr) {
@@ -254,10 +257,10 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       uint32_t mask;
       if (packed) {
         const bool want = M == Mode::Count && keep != nullptr && qy.nseg == 1;
-        mask = light_mask_packed(v, w, shf & 31u, lo, hi, qy.aux, al, want ? keep : nullptr);
+        mask = light_mask_packed<F>(v, w, shf & 31u, lo, hi, qy.aux, al, want ? keep : nullptr);
         if (M == Mode::Count && rp) rp->kept = want;
       } else {
-        mask = light_mask_pairs(v, w.a, w.b, lo, hi, qy.aux, al);
+        mask = light_mask_pairs<F>(v, w.a, w.b, lo, hi, qy.aux, al);
       }
       if (M == Mode::Count) {
         acc += (uint32_t)__popc(mask);
@@ -285,11 +288,11 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       hm &= hm - 1;
       const uint32_t ca = __shfl(w.a, src, kWave), cb = __shfl(w.b, src, kWave);
       const uint32_t cl = __shfl(lo, src, kWave), ch = __shfl(hi, src, kWave);
-      const uint32_t cx = __shfl(qy.aux, src, kWave);
+      const uint32_t cx = F ? __shfl(qy.aux, src, kWave) : 0u;
       auto is_hit = [&](uint32_t j) {
         const uint2 e = v.se[j];
         return e.x <= ch && e.y >= cl &&
-               (v.flt_kind == BIVX_FILTER_NONE || filter_accept(v, cl, ch, cx, e.x, e.y, v.id[j]));
+               (!F || filter_accept(v, cl, ch, cx, e.x, e.y, v.id[j]));
       };
       if (M == Mode::Count) {
         uint32_t c = 0;
@@ -340,13 +343,14 @@ __device__ __forceinline__ void stage_descriptors(const IndexView &v, SegDesc *s
   }
 }
 
+template <bool F>
 __device__ __forceinline__ Query load_query(const IndexView &v, const uint32_t *cs, const uint32_t *qchrom,
                                             const uint32_t *qlow, const uint32_t *qhigh, size_t q, bool valid) {
   Query qy{0u, 0u, 0u, 0u, 0u};
   if (valid) {
     qy.lo = qlow[q];
     qy.hi = qhigh[q];
-    if (v.flt_qaux) qy.aux = v.flt_qaux[q];
+    if (F && v.flt_qaux) qy.aux = v.flt_qaux[q];
     const uint32_t c = qchrom ? qchrom[q] : 0u;
     if (c < v.nchrom) {
       qy.s0 = cs[c];
@@ -357,7 +361,7 @@ __device__ __forceinline__ Query load_query(const IndexView &v, const uint32_t *
 }
 
 // ---- two-pass kernels ----------------------------------------------------------------------------------
-template <Mode M, bool LDS_DESC>
+template <Mode M, bool LDS_DESC, bool F>
 __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t *__restrict__ qchrom,
                                                      const uint32_t *__restrict__ qlow,
                                                      const uint32_t *__restrict__ qhigh, size_t nq,
@@ -371,10 +375,10 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
   if (LDS_DESC) __syncthreads();
   const size_t q = (size_t)blockIdx.x * kQThreads + threadIdx.x;
   const bool valid = q < nq;
-  const Query qy = load_query(v, cs, qchrom, qlow, qhigh, q, valid);
+  const Query qy = load_query<F>(v, cs, qchrom, qlow, qhigh, q, valid);
   uint64_t pos = 0;
   if (M == Mode::Fill && valid) pos = offsets[q];
-  const uint32_t r = enumerate_hits<M>(v, segs, qy, out, pos, ~0ull, nullptr);
+  const uint32_t r = enumerate_hits<M, F>(v, segs, qy, out, pos, ~0ull, nullptr);
   if (valid && M != Mode::Fill) out[q] = r;
 }
 
@@ -386,7 +390,8 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
 // another XCD's status word goes to memory (per-XCD L2s are not coherent), so the number of dependent polls,
 // not their width, is what costs. Larger batches run as consecutive launches; each starts from the running
 // total its predecessor left in offsets[q_begin].
-//   ws[0] (low 32 bits): tile ticket. ws[1 + t]: kStValid | hits of tile t, written and polled as ONE 8-byte
+//   ws[kWsTicket] (low 32 bits): tile ticket. ws[kWsDone]: tiles that have left. ws[kWsStatus + t]: kStValid |
+//   hits of tile t, written and polled as ONE 8-byte
 //   agent-scope atomic, so the value needs no separate fence. Tiles take tickets in launch order: every
 //   predecessor of a polling tile is already resident, the wait cannot deadlock; spins are bounded anyway.
 #ifndef BIVX_FUSED_THREADS
@@ -401,6 +406,9 @@ constexpr int kFR = BIVX_FUSED_ROUNDS;  // consecutive queries per thread
 constexpr int kFTile = kFThreads * kFR;
 constexpr unsigned kFMaxTiles = 1024;
 constexpr uint64_t kStValid = 1ull << 63;
+// workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
+// on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
+constexpr uint32_t kWsTicket = 0, kWsDone = 16, kWsStatus = 32;
 constexpr uint32_t kSpinCap = 1u << 20;
 
 __device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
@@ -420,16 +428,17 @@ __device__ unsigned long long g_stamps[kFMaxTiles * 8];
 #define BIVX_STAMP(k)
 #endif
 
-template <bool LDS_DESC>
+template <bool LDS_DESC, bool F>
 __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
                                                            const uint32_t *__restrict__ qhigh, size_t q_begin,
                                                            size_t q_end, uint64_t *__restrict__ offsets,
                                                            uint32_t *__restrict__ hits, uint64_t cap,
-                                                           uint64_t *__restrict__ ws) {
+                                                           uint64_t *__restrict__ ws, int self_clean) {
   __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
   __shared__ uint32_t s_cs[LDS_DESC ? kLdsChroms + 1 : 1];
   __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_last;  // this tile finished its prefix sweep last: it zeroes the workspace for the next call
   __shared__ uint32_t s_wsum[kFWaves];
   __shared__ uint64_t s_base;
   __shared__ uint4 s_keep[kFR][kFThreads];  // ids of each query's first kKeep hits (thread-private slots)
@@ -437,17 +446,18 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
   const int wave = threadIdx.x >> 6;
 
   BIVX_STAMP(0);
+  if (threadIdx.x == 0) s_last = 0;
 #ifdef BIVX_NO_TICKET  // timing experiment only: relies on in-order dispatch, which HIP does not promise
   if (threadIdx.x == 0) s_tile = blockIdx.x;
 #else
-  if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<unsigned int *>(ws), 1u);
+  if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTicket), 1u);
 #endif
   const SegDesc *segs;
   const uint32_t *cs;
   stage_descriptors<LDS_DESC>(v, s_seg, s_cs, segs, cs);
   __syncthreads();
   const uint32_t tile = s_tile;
-  uint64_t *status = ws + 1;
+  uint64_t *status = ws + kWsStatus;
   BIVX_STAMP(1);
 
   // phase 1: count the thread's kFR consecutive queries
@@ -457,10 +467,10 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
   uint32_t cnt[kFR];
   uint32_t tsum = 0;
 #pragma unroll
-  for (int r = 0; r < kFR; ++r) qy[r] = load_query(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
+  for (int r = 0; r < kFR; ++r) qy[r] = load_query<F>(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
 #pragma unroll
   for (int r = 0; r < kFR; ++r) {
-    cnt[r] = enumerate_hits<Mode::Count>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
+    cnt[r] = enumerate_hits<Mode::Count, F>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
                                          reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x]));
     tsum += cnt[r];
   }
@@ -562,8 +572,22 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
       }
       qy[r].nseg = 0;
     }
-    (void)enumerate_hits<Mode::Fill>(v, segs, qy[r], hits, pos, cap, nullptr);
+    (void)enumerate_hits<Mode::Fill, F>(v, segs, qy[r], hits, pos, cap, nullptr);
     pos += cnt[r];
+  }
+  // self-cleaning workspace: every tile bumps `done` when it leaves (its sweep is long over); the tile that
+  // sees gridDim.x - 1 knows nobody reads the words any more and zeroes them for the next launch. Off the
+  // critical path: nothing waits for this but the end of the kernel.
+  if (self_clean) {
+    if (threadIdx.x == 0 && atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1) s_last = 1;
+    __syncthreads();
+    if (s_last) {
+      for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) status[t] = 0;
+      if (threadIdx.x == 0) {
+        ws[kWsTicket] = 0;
+        ws[kWsDone] = 0;
+      }
+    }
   }
   BIVX_STAMP(6);
 #ifdef BIVX_STAMPS
@@ -668,12 +692,16 @@ template <Mode M>
 int launch_query(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                  size_t q, const uint64_t *d_offsets, uint32_t *d_out, hipStream_t s) {
   if (q == 0) return 0;
-  if (fits_lds(v))
-    hipLaunchKernelGGL((k_query<M, true>), dim3(tiles_for(q)), dim3(kQThreads), 0, s, v, d_qchrom, d_qlow, d_qhigh,
-                       q, d_offsets, d_out);
+  const dim3 grid(tiles_for(q)), block(kQThreads);
+  const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;  // filter code is compiled out when unused
+  if (lds && !flt)
+    hipLaunchKernelGGL((k_query<M, true, false>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_out);
+  else if (lds)
+    hipLaunchKernelGGL((k_query<M, true, true>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_out);
+  else if (!flt)
+    hipLaunchKernelGGL((k_query<M, false, false>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_out);
   else
-    hipLaunchKernelGGL((k_query<M, false>), dim3(tiles_for(q)), dim3(kQThreads), 0, s, v, d_qchrom, d_qlow, d_qhigh,
-                       q, d_offsets, d_out);
+    hipLaunchKernelGGL((k_query<M, false, true>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_out);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -697,12 +725,12 @@ int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_q
 
 size_t fused_workspace_bytes(size_t q) {
   (void)q;
-  return ((size_t)kFMaxTiles + 2) * sizeof(uint64_t);
+  return ((size_t)kFMaxTiles + kWsStatus) * sizeof(uint64_t);
 }
 
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
-                       void *d_ws, hipStream_t s) {
+                       void *d_ws, bool self_clean, hipStream_t s) {
   if (q == 0) {
     BIVX_HIP(hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), s));
     return 0;
@@ -712,13 +740,23 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
   for (size_t q0 = 0; q0 < q; q0 += per_launch) {
     const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
     const unsigned tiles = (unsigned)((q1 - q0 + kFTile - 1) / kFTile);
-    BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + 1) * sizeof(uint64_t), s));  // ticket + status words
-    if (fits_lds(v))
-      hipLaunchKernelGGL((k_query_fused<true>), dim3(tiles), dim3(kFThreads), 0, s, v, d_qchrom, d_qlow, d_qhigh, q0,
-                         q1, d_offsets, d_hits, cap, ws);
+    // ticket, done counter, status words: zeroed here, or left zeroed by the previous launch (self_clean)
+    if (!self_clean) BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kWsStatus) * sizeof(uint64_t), s));
+    const dim3 grid(tiles), block(kFThreads);
+    const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
+    const int sc = self_clean ? 1 : 0;
+    if (lds && !flt)
+      hipLaunchKernelGGL((k_query_fused<true, false>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets,
+                         d_hits, cap, ws, sc);
+    else if (lds)
+      hipLaunchKernelGGL((k_query_fused<true, true>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets,
+                         d_hits, cap, ws, sc);
+    else if (!flt)
+      hipLaunchKernelGGL((k_query_fused<false, false>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets,
+                         d_hits, cap, ws, sc);
     else
-      hipLaunchKernelGGL((k_query_fused<false>), dim3(tiles), dim3(kFThreads), 0, s, v, d_qchrom, d_qlow, d_qhigh, q0,
-                         q1, d_offsets, d_hits, cap, ws);
+      hipLaunchKernelGGL((k_query_fused<false, true>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets,
+                         d_hits, cap, ws, sc);
   }
   BIVX_HIP(hipGetLastError());
   return 0;

@@ -183,7 +183,7 @@ class IntervalIndex:
     def query_workspace_bytes(self, q: int) -> int:
         return int(self._L.bivx_query_workspace_bytes(int(q)))
 
-    def query_device(self, qlow, qhigh, offsets, hits, workspace, qchrom=None, sort_by_id: bool = False):
+    def query_device(self, qlow, qhigh, offsets, hits, workspace=None, qchrom=None, sort_by_id: bool = False):
         """Single-pass count+prefix+fill into caller-owned buffers (bivx_query_dev); asynchronous.
         offsets[-1] is the true hit total even if it exceeds hits.numel() (then only a prefix was written)."""
         self._ensure_built()
@@ -194,10 +194,12 @@ class IntervalIndex:
             _check_dev_tensor(qchrom, "qchrom", q)
         _check_dev_tensor(offsets, "offsets", q + 1, 8)
         _check_dev_tensor(hits, "hits")
-        _check_dev_tensor(workspace, "workspace", None, 1)
+        if workspace is not None:
+            _check_dev_tensor(workspace, "workspace", None, 1)
         s = C.c_void_p(torch.cuda.current_stream(qlow.device).cuda_stream)
         capi.check(self._L.bivx_query_dev(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q, _tptr(offsets),
-                                          _tptr(hits), hits.numel(), _tptr(workspace), workspace.numel(), s))
+                                          _tptr(hits), hits.numel(), _tptr(workspace),
+                                          0 if workspace is None else workspace.numel(), s))
         if sort_by_id:
             capi.check(self._L.bivx_sort_hits_dev(self._h, _tptr(offsets), _tptr(hits), q, s))
         return offsets, hits

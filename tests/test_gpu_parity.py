@@ -339,6 +339,35 @@ def test_single_pass_equals_two_pass_and_oracle(IntervalIndex, oracle):
         assert np.array_equal(got.astype(np.int64), sel[oracle.sorted_csr(off_o, hits_o)])
 
 
+def test_single_pass_index_owned_workspace(IntervalIndex):
+    """workspace=None: the index keeps a self-cleaning prefix workspace per stream; results must not change over
+    repeated calls, different batch sizes, two streams, or a rebuild in between."""
+    import torch
+    from binary_amd import synth
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    low, high = synth.gen_intervals(300_000, 30_000_000, 1000)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        side = torch.cuda.Stream()
+        for rep, nq in enumerate((1_300_003, 70_000, 1024, 1, 1_300_003)):
+            qlo, qhi = synth.gen_range_queries(nq, 30_000_000, 1000, chrom_index=rep)
+            ref_off, ref_hits = idx.find_overlaps(qlo, qhi, sort_by_id=False)
+            for stream in (torch.cuda.current_stream(), side):
+                with torch.cuda.stream(stream):
+                    off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+                    hits = torch.empty(max(int(ref_off[-1]), 1), dtype=torch.int32, device=dev)
+                    for _ in range(3):
+                        idx.query_device(to(qlo), to(qhi), off, hits)
+                    stream.synchronize()
+                assert np.array_equal(off.cpu().numpy().astype(np.uint64), ref_off)
+                assert np.array_equal(hits.cpu().numpy().view(np.uint32)[: int(ref_off[-1])], ref_hits)
+            if rep == 2:
+                idx.insert_node(low[:1000], high[:1000])  # forces a rebuild; workspaces are reset with it
+                idx.build()
+
+
 def test_single_pass_repeated_calls_are_deterministic(IntervalIndex):
     import torch
     from binary_amd import synth
