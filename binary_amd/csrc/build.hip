@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void k_build_table(const uint2 *__restric
 }
 
 // ---- packed records ----------------------------------------------------------------------------------------
-// rec[i] = ((low - cell_low) | (high - low) << 16, id) for slots of kSegPacked segments ((0, id) elsewhere)
+// rec[i] = ((low & 0xFFFF) | (high - low) << 16, id) for slots of kSegPacked segments ((0, id) elsewhere)
 __global__ __launch_bounds__(kThreads) void k_pack_records(const uint2 *__restrict__ se,
                                                            const uint32_t *__restrict__ id,
                                                            const SegDesc *__restrict__ seg, uint32_t nseg,
@@ -272,9 +272,7 @@ __global__ __launch_bounds__(kThreads) void k_pack_records(const uint2 *__restri
   uint32_t r = 0;
   if (d.shift & kSegPacked) {
     const uint2 e = se[i];
-    const uint32_t sh = d.shift & 31u;
-    const uint32_t rel = e.x - d.base;
-    r = (rel - ((rel >> sh) << sh)) | ((e.y - e.x) << 16);
+    r = (e.x & 0xFFFFu) | ((e.y - e.x) << 16);
   }
   rec[i] = make_uint2(r, id[i]);
 }

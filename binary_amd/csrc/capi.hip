@@ -238,7 +238,7 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &pl
       uint32_t sh = 0;
       while (sh < 31 && (span >> sh) + 1 > target) ++sh;
       d.shift = sh;
-      if (sh <= 16 && ml <= 0xFFFFu && ninv == 0) d.shift |= kSegPacked;
+      if (ml <= 0xFFFFu && ninv == 0) d.shift |= kSegPacked;
       d.ncell = (uint32_t)((span >> sh) + 1);
       if (table_off + d.ncell + 1 > 0xFFFFFFFFull) {
         set_error("bucket directory too large");

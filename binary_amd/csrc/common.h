@@ -41,8 +41,8 @@ struct SegDesc {        // 32 B, read as two dwordx4
   uint32_t ncell;
 };
 static_assert(sizeof(SegDesc) == 32, "SegDesc layout");
-// Segment also has packed records rec[i] = ((low - cell_low) | (high - low) << 16, id): needs shift <= 16,
-// maxlen <= 65535 and no low > high entry.
+// Segment also has packed records rec[i] = ((low & 0xFFFF) | (high - low) << 16, id): needs maxlen <= 65535 and no
+// low > high entry; a query decodes them when its window's cells cover at most 65536 coordinates.
 constexpr uint32_t kSegPacked = 1u << 8;
 
 // Device view of a built index, passed to kernels by value.

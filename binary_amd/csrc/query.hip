@@ -23,7 +23,7 @@ namespace {
 
 constexpr int kQThreads = 256;
 constexpr int kQWaves = kQThreads / kWave;
-constexpr uint32_t kLight = 32;      // window slots a lane reads by itself; longer windows go to the wavefront
+constexpr uint32_t kLight = 64;      // window slots a lane reads by itself; longer windows go to the wavefront
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
 constexpr uint32_t kLdsChroms = 511; // ... with chrom_seg (2 KiB); larger indexes read them from global
 
@@ -44,13 +44,13 @@ __device__ __forceinline__ SegDesc load_seg(const SegDesc *p) {
 // not hits fail the predicate, which is evaluated on every candidate anyway.
 struct Window {
   uint32_t a, b;        // candidate slots [a, b)
-  uint32_t t1, t2;      // first slots of cells ca+1, ca+2 (valid when span <= 3)
-  uint32_t cell0_low;   // coordinate of the start of cell ca
+  uint32_t cell0_low;   // coordinate of the start of cell ca: every candidate's low is >= it
   uint32_t span;        // number of cells, 0 = empty window
+  bool narrow;          // the window's cells cover at most 65536 coordinates (packed records are decodable)
 };
 
 __device__ __forceinline__ Window seg_window(const IndexView &v, const SegDesc &d, uint32_t lo, uint32_t hi) {
-  Window w{0u, 0u, 0u, 0u, 0u, 0u};
+  Window w{0u, 0u, 0u, 0u, false};
   const uint32_t x = lo > d.maxlen ? lo - d.maxlen : 0u;
   if (hi < d.base || x > d.last || hi < x) return w;
   const uint32_t sh = d.shift & 31u;
@@ -61,10 +61,9 @@ __device__ __forceinline__ Window seg_window(const IndexView &v, const SegDesc &
   const u32x4_a4 tq = *reinterpret_cast<const u32x4_a4 *>(t + ca);
   w.span = cb - ca;
   w.a = tq.x;
-  w.t1 = tq.y;
-  w.t2 = tq.z;
   w.b = w.span == 1 ? tq.y : w.span == 2 ? tq.z : w.span == 3 ? tq.w : t[cb];
   w.cell0_low = d.base + (ca << sh);
+  w.narrow = ((uint64_t)w.span << sh) <= 65536ull;
   return w;
 }
 
@@ -110,11 +109,11 @@ __device__ __forceinline__ bool filter_accept(const IndexView &v, uint32_t lo, u
 
 // hit mask of a short window over 8-byte (low, high) pairs; bit j <-> slot al + j, al = a rounded down to 2
 template <bool F>
-__device__ __forceinline__ uint32_t light_mask_pairs(const IndexView &v, uint32_t a, uint32_t b, uint32_t lo,
+__device__ __forceinline__ uint64_t light_mask_pairs(const IndexView &v, uint32_t a, uint32_t b, uint32_t lo,
                                                      uint32_t hi, uint32_t qaux, uint32_t &al) {
   const uint4 *pairs = reinterpret_cast<const uint4 *>(v.se);
   al = a & ~1u;
-  uint32_t mask = 0;
+  uint64_t mask = 0;
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < kLight; c0 += 8) {
     if (al + c0 < b) {
@@ -130,10 +129,10 @@ __device__ __forceinline__ uint32_t light_mask_pairs(const IndexView &v, uint32_
         if (s < b) {
           if (s >= a && r[j].x <= hi && r[j].y >= lo &&
               (!F || filter_accept(v, lo, hi, qaux, r[j].x, r[j].y, v.id[s])))
-            mask |= 1u << (c0 + 2 * j);
+            mask |= 1ull << (c0 + 2 * j);
           if (s + 1 < b && r[j].z <= hi && r[j].w >= lo &&
               (!F || filter_accept(v, lo, hi, qaux, r[j].z, r[j].w, v.id[s + 1])))
-            mask |= 1u << (c0 + 2 * j + 1);
+            mask |= 1ull << (c0 + 2 * j + 1);
         }
       }
     }
@@ -172,8 +171,8 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const 
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const uint32_t i = s + e;
-        const uint32_t cell = (i >= w.t1 ? 1u : 0u) + (i >= w.t2 ? 1u : 0u);
-        const uint32_t low = w.cell0_low + (cell << sh) + (rr[e] & 0xFFFFu);
+        // the record keeps low's 16 low bits; every candidate's low lies in [cell0_low, cell0_low + 65536)
+        const uint32_t low = w.cell0_low + ((rr[e] - w.cell0_low) & 0xFFFFu);
         const uint32_t high = low + (rr[e] >> 16);
         if (i >= w.a && i < w.b && low <= hi && high >= lo &&
             (!F || filter_accept(v, lo, hi, qaux, low, high, ii[e]))) {
@@ -190,19 +189,27 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const 
 }
 
 template <bool F>
-__device__ __forceinline__ uint32_t light_mask_packed(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
+__device__ __forceinline__ uint64_t light_mask_packed(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
                                                       uint32_t hi, uint32_t qaux, uint32_t &al, uint32_t *keep) {
   al = w.a & ~1u;
-  uint32_t mask = 0, n = 0;
+  uint64_t mask = 0;
+  uint32_t n = 0;
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < kLight; c0 += 8) {
     if (al + c0 < w.b) {
       uint4 r[4];
       packed_load_chunk(v, al + c0, w.b, r);
-      mask |= packed_eval_chunk<F>(v, w, sh, lo, hi, qaux, al + c0, r, keep, n) << c0;
+      mask |= (uint64_t)packed_eval_chunk<F>(v, w, sh, lo, hi, qaux, al + c0, r, keep, n) << c0;
     }
   }
   return mask;
+}
+
+// orders one wavefront's LDS / global accesses: what lanes wrote before is visible to all lanes after
+__device__ __forceinline__ void wave_sync_mem() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 enum class Mode { Count, Fill, Any };
@@ -218,9 +225,10 @@ struct Query {
 // valid when the query touched one segment and its window fitted the lane budget.
 struct Replay {
   uint32_t al;    // aligned first slot of the window
-  uint32_t mask;  // bit j set: slot al + j is a hit
+  uint64_t mask;  // bit j set: slot al + j is a hit
   bool ok;
   bool kept;      // ids of the first min(hits, kKeep) hits were written to the caller's `keep` slots
+  bool packed;    // the window was read from packed records: ids sit in rec[].y
 };
 
 // The whole hit enumeration of one query per lane, wavefront-converged (all 64 lanes must call it).
@@ -239,10 +247,11 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
     rp->mask = 0;
     rp->ok = qy.nseg <= 1;
     rp->kept = false;
+    rp->packed = false;
   }
   // the segment loop is wavefront-uniform so the cooperative part may use __ballot / __shfl
   for (uint32_t k = 0; __any(k < qy.nseg); ++k) {
-    Window w{0u, 0u, 0u, 0u, 0u, 0u};
+    Window w{0u, 0u, 0u, 0u, false};
     uint32_t shf = 0;
     if (k < qy.nseg) {
       const SegDesc d = load_seg(segs + qy.s0 + k);
@@ -250,27 +259,30 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       shf = d.shift;
     }
     const bool nonempty = w.span != 0 && w.b > w.a;
-    const bool packed = (shf & kSegPacked) != 0 && w.span <= 3;
+    const bool packed = (shf & kSegPacked) != 0 && w.narrow;
     const bool heavy = nonempty && (w.b - (w.a & ~1u)) > kLight;
     if (nonempty && !heavy) {
       uint32_t al;
-      uint32_t mask;
+      uint64_t mask;
       if (packed) {
         const bool want = M == Mode::Count && keep != nullptr && qy.nseg == 1;
         mask = light_mask_packed<F>(v, w, shf & 31u, lo, hi, qy.aux, al, want ? keep : nullptr);
-        if (M == Mode::Count && rp) rp->kept = want;
+        if (M == Mode::Count && rp) {
+          rp->kept = want;
+          rp->packed = true;
+        }
       } else {
         mask = light_mask_pairs<F>(v, w.a, w.b, lo, hi, qy.aux, al);
       }
       if (M == Mode::Count) {
-        acc += (uint32_t)__popc(mask);
+        acc += (uint32_t)__popcll(mask);
         if (rp) {
           rp->al = al;
           rp->mask = mask;
         }
       } else {
         while (mask) {
-          const uint32_t j = (uint32_t)__ffs((int)mask) - 1u;
+          const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
           mask &= mask - 1;
           const uint32_t hid = packed ? v.rec[al + j].y : v.id[al + j];  // packed: the line is already here
           if (M == Mode::Any) acc = min(acc, hid);
@@ -405,6 +417,8 @@ constexpr int kFWaves = kFThreads / kWave;
 constexpr int kFR = BIVX_FUSED_ROUNDS;  // consecutive queries per thread
 constexpr int kFTile = kFThreads * kFR;
 constexpr unsigned kFMaxTiles = 1024;
+constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per round before streaming them out
+constexpr uint32_t kStageMin = 320;  // ... when it has at least this many (5 per lane); below that lanes store directly
 constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
 // on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
@@ -428,8 +442,9 @@ __device__ unsigned long long g_stamps[kFMaxTiles * 8];
 #define BIVX_STAMP(k)
 #endif
 
+// two workgroups per CU (8 waves per SIMD): keeps the kernel within 64 VGPRs
 template <bool LDS_DESC, bool F>
-__global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
+__global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThreads / 256)) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
                                                            const uint32_t *__restrict__ qhigh, size_t q_begin,
                                                            size_t q_end, uint64_t *__restrict__ offsets,
@@ -442,6 +457,7 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
   __shared__ uint32_t s_wsum[kFWaves];
   __shared__ uint64_t s_base;
   __shared__ uint4 s_keep[kFR][kFThreads];  // ids of each query's first kKeep hits (thread-private slots)
+  __shared__ uint32_t s_out[kFWaves][kStage];  // per-wavefront staging of the output ids
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
@@ -526,8 +542,12 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
   __syncthreads();
   BIVX_STAMP(5);
 
-  // phase 2: offsets and hit ids. A query whose window was recorded replays its hit mask (ids only); the
-  // others enumerate again with the lines of phase 1 still in this CU's L1 / this XCD's L2.
+  // phase 2: offsets and hit ids.
+  // A query whose window was recorded replays its hit mask: the ids of its first hits wait in LDS, later ones
+  // are re-read next to their records. When every lane of a wavefront replays (the common case), the ids are
+  // first laid out in LDS exactly as they will sit in the output — the 64 lists are adjacent there — and then
+  // streamed out with coalesced stores, kStage ids per round, instead of 64 lanes each storing 4 bytes at a time
+  // into 64 different lines. Other wavefronts (several segments, long windows) enumerate again, directly.
   uint64_t pos = s_base + local;
 #pragma unroll
   for (int r = 0; r < kFR; ++r) {
@@ -536,43 +556,53 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
       offsets[q] = pos;
       if (q == q_end - 1) offsets[q_end] = pos + cnt[r];
     }
-    if (rp[r].ok) {
-      uint32_t mask = rp[r].mask, k = 0;
-      if (rp[r].kept) {
-        // the first kKeep ids were captured while counting: no load at all for most queries
-        const uint4 h = s_keep[r][threadIdx.x];
-        const uint32_t hh[4] = {h.x, h.y, h.z, h.w};
-        const uint32_t n = cnt[r] < kKeep ? cnt[r] : kKeep;
-#pragma unroll
-        for (uint32_t e = 0; e < kKeep; ++e) {
-          if (e < n) {
-            if (pos + e < cap) hits[pos + e] = hh[e];
+    const uint32_t *kept = reinterpret_cast<const uint32_t *>(&s_keep[r][threadIdx.x]);
+    auto hit_id = [&](uint32_t k, uint32_t j) -> uint32_t {  // id of the k-th hit, which sits in slot al + j
+      if (rp[r].kept && k < kKeep) return kept[k];
+      return rp[r].packed ? v.rec[rp[r].al + j].y : v.id[rp[r].al + j];
+    };
+    const bool all_replay = __all(rp[r].ok);
+    const uint64_t wpos0 = __shfl((unsigned long long)pos, 0, kWave);
+    const uint32_t loff = (uint32_t)(pos - wpos0);
+    const uint32_t wtotal = __shfl(loff + cnt[r], kWave - 1, kWave);
+    if (all_replay && wtotal >= kStageMin) {
+      uint32_t *buf = s_out[wave];
+      for (uint32_t base = 0; base < wtotal; base += kStage) {
+        if (cnt[r] != 0 && loff < base + kStage && loff + cnt[r] > base) {
+          uint64_t mask = rp[r].mask;
+          uint32_t k = 0;
+          while (mask) {
+            const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
             mask &= mask - 1;
+            const uint32_t o = loff + k;
+            if (o >= base && o < base + kStage) buf[o - base] = hit_id(k, j);
+            ++k;
           }
         }
-        k = n;
-      }
-      // (remaining) ids four at a time: the loads of one group are independent of each other
-      while (mask) {
-        uint32_t j[4], hid[4];
-        int n = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          j[e] = mask ? (uint32_t)__ffs((int)mask) - 1u : 0u;
-          if (mask) ++n;
-          mask &= mask - 1;
+        wave_sync_mem();
+        const uint32_t nthis = wtotal - base < kStage ? wtotal - base : kStage;
+        for (uint32_t i = lane; i < nthis; i += kWave) {
+          const uint64_t p = wpos0 + base + i;
+          if (p < cap) hits[p] = buf[i];
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < n) hid[e] = v.id[rp[r].al + j[e]];  // v.id mirrors the ids of the packed records
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < n && pos + k + e < cap) hits[pos + k + e] = hid[e];
-        k += n;
+        wave_sync_mem();
       }
-      qy[r].nseg = 0;
+    } else {
+      // few ids per lane (or a wavefront that holds general-path queries): every lane stores its own list
+      if (rp[r].ok) {
+        uint64_t mask = rp[r].mask;
+        uint32_t k = 0;
+        while (mask) {
+          const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
+          mask &= mask - 1;
+          const uint32_t hid = hit_id(k, j);
+          if (pos + k < cap) hits[pos + k] = hid;
+          ++k;
+        }
+        qy[r].nseg = 0;
+      }
+      if (!all_replay) (void)enumerate_hits<Mode::Fill, F>(v, segs, qy[r], hits, pos, cap, nullptr);
     }
-    (void)enumerate_hits<Mode::Fill, F>(v, segs, qy[r], hits, pos, cap, nullptr);
     pos += cnt[r];
   }
   // self-cleaning workspace: every tile bumps `done` when it leaves (its sweep is long over); the tile that
@@ -599,12 +629,6 @@ __global__ __launch_bounds__(kFThreads) void k_query_fused(IndexView v, const ui
 
 constexpr uint32_t kSortLane = 24;    // <= this many hits: the owning lane insertion-sorts in place
 constexpr uint32_t kSortLds = 2048;   // <= this many: the wavefront bitonic-sorts through LDS
-
-__device__ __forceinline__ void wave_sync_mem() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 // Ascending sort of s[0..n) by one wavefront: the normalised bitonic network (every comparator puts the
 // minimum at the lower index), so virtual +inf pads at indices >= n never move and comparators that
