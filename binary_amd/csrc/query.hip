@@ -409,12 +409,10 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
 #ifndef BIVX_FUSED_THREADS
 #define BIVX_FUSED_THREADS 1024
 #endif
-#ifndef BIVX_FUSED_ROUNDS
-#define BIVX_FUSED_ROUNDS 1
-#endif
 constexpr int kFThreads = BIVX_FUSED_THREADS;
 constexpr int kFWaves = kFThreads / kWave;
-constexpr int kFR = BIVX_FUSED_ROUNDS;  // consecutive queries per thread
+constexpr int kFR = 1;  // queries per thread. (More per thread was measured and did not pay: a wavefront here is
+                        // latency-bound, and the output staging below assumes the 64 lists of a wavefront are adjacent.)
 constexpr int kFTile = kFThreads * kFR;
 constexpr unsigned kFMaxTiles = 1024;
 constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per round before streaming them out
@@ -627,8 +625,9 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
 
 // ---- per-query ascending-id ordering of a CSR hit list ------------------------------------------------
 
+constexpr uint32_t kRankMax = 48;     // lists up to this long are rank-sorted by their lane (fast path)
 constexpr uint32_t kSortLane = 24;    // <= this many hits: the owning lane insertion-sorts in place
-constexpr uint32_t kSortLds = 2048;   // <= this many: the wavefront bitonic-sorts through LDS
+constexpr uint32_t kSortLds = 4096;   // <= this many: the wavefront bitonic-sorts through LDS (16 KiB per wavefront)
 
 // Ascending sort of s[0..n) by one wavefront: the normalised bitonic network (every comparator puts the
 // minimum at the lower index), so virtual +inf pads at indices >= n never move and comparators that
@@ -671,12 +670,43 @@ __global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restr
   const size_t q = (size_t)blockIdx.x * kQThreads + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  uint64_t o0 = 0, o1 = 0;
+  uint64_t o0, o1;
   if (q < nq) {
     o0 = offsets[q];
     o1 = offsets[q + 1];
+  } else {
+    o0 = o1 = offsets[nq];  // lanes past the batch own an empty list at the very end: regions stay monotone
   }
   const uint64_t cnt = o1 - o0;
+
+  // Fast path, the usual case: every list of the wavefront is short and the 64 lists (adjacent in memory) fit the
+  // wavefront's LDS stage. The region is loaded with coalesced reads; every lane RANK-sorts its own list out of
+  // LDS (rank = how many elements are smaller; ids are distinct inside a query) — n^2 independent LDS reads and
+  // no dependent chain, unlike an insertion sort — into a second stage, which is streamed back coalesced.
+  {
+    const uint64_t wb = __shfl((unsigned long long)o0, 0, kWave);
+    const uint64_t we = __shfl((unsigned long long)o1, kWave - 1, kWave);
+    const bool lanes_ok = __all(cnt <= kRankMax) != 0;
+    if (lanes_ok && we - wb <= kSortLds / 2) {
+      const uint32_t wtotal = (uint32_t)(we - wb);
+      uint32_t *in = lds[wave], *outb = lds[wave] + kSortLds / 2;
+      if (__any(cnt > 1)) {
+        for (uint32_t i = lane; i < wtotal; i += kWave) in[i] = hits[wb + i];
+        wave_sync_mem();
+        const uint32_t off = (uint32_t)(o0 - wb), n = (uint32_t)cnt;
+        for (uint32_t i = 0; i < n; ++i) {
+          const uint32_t x = in[off + i];
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < n; ++j) rank += in[off + j] < x ? 1u : 0u;
+          outb[off + rank] = x;
+        }
+        wave_sync_mem();
+        for (uint32_t i = lane; i < wtotal; i += kWave) hits[wb + i] = outb[i];
+      }
+      return;
+    }
+  }
+
   if (cnt > 1 && cnt <= kSortLane) {
     uint32_t *h = hits + o0;
     for (uint32_t j = 1; j < (uint32_t)cnt; ++j) {
