@@ -234,7 +234,13 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &pl
       d.last = mx;
       d.maxlen = ml;
       const uint64_t span = (uint64_t)mx - mn;
-      const uint64_t target = cnt / 2 > 1 ? cnt / 2 : 1;
+      // directory density: at most cnt / kSlotsPerCell cells, i.e. kSlotsPerCell .. 2*kSlotsPerCell slots per cell
+      static const uint64_t kSlotsPerCell = [] {
+        const char *e = std::getenv("BIVX_SLOTS_PER_CELL");  // tuning knob; default 2
+        const long v = e ? std::atol(e) : 2;
+        return (uint64_t)(v < 1 ? 1 : v);
+      }();
+      const uint64_t target = cnt / kSlotsPerCell > 1 ? cnt / kSlotsPerCell : 1;
       uint32_t sh = 0;
       while (sh < 31 && (span >> sh) + 1 > target) ++sh;
       d.shift = sh;

@@ -140,11 +140,12 @@ __device__ __forceinline__ uint64_t light_mask_pairs(const IndexView &v, uint32_
   return mask;
 }
 
-// the same over packed records of a window of at most 3 cells. A packed record is 8 bytes:
-// (off16 | len16 << 16, id) — the interval relative to its directory cell, and its append-order id right
-// beside it, so the cache line that answers "is it a hit" also says which interval it is.
+// the same over packed records. A packed record is 8 bytes: (low & 0xFFFF | (high - low) << 16, id) — the
+// interval's low 16 coordinate bits and its length, and its append-order id right beside it, so the cache line
+// that answers "is it a hit" also says which interval it is. A window whose cells cover at most 65536
+// coordinates decodes low uniquely: low = cell0_low + ((record - cell0_low) & 0xFFFF).
 // bit j <-> slot al + j, al = a rounded down to 2. If `keep` is given, the ids of the first kKeep hits are
-// written there (ascending slot order) as they are found; *nkept receives min(hits, kKeep).
+// written there (ascending slot order) as they are found.
 constexpr uint32_t kKeep = 4;
 
 // one chunk = 8 consecutive slots starting at the even slot c = al + c0, as four 16-byte loads
@@ -159,7 +160,7 @@ __device__ __forceinline__ void packed_load_chunk(const IndexView &v, uint32_t c
 
 // evaluates the predicate on a loaded chunk; returns the chunk's 8-bit hit mask (bit k <-> slot c + k)
 template <bool F>
-__device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
+__device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const Window &w, uint32_t lo,
                                                       uint32_t hi, uint32_t qaux, uint32_t c, const uint4 (&r)[4],
                                                       uint32_t *keep, uint32_t &n) {
   uint32_t m = 0;
@@ -189,7 +190,7 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const 
 }
 
 template <bool F>
-__device__ __forceinline__ uint64_t light_mask_packed(const IndexView &v, const Window &w, uint32_t sh, uint32_t lo,
+__device__ __forceinline__ uint64_t light_mask_packed(const IndexView &v, const Window &w, uint32_t lo,
                                                       uint32_t hi, uint32_t qaux, uint32_t &al, uint32_t *keep) {
   al = w.a & ~1u;
   uint64_t mask = 0;
@@ -199,7 +200,7 @@ __device__ __forceinline__ uint64_t light_mask_packed(const IndexView &v, const 
     if (al + c0 < w.b) {
       uint4 r[4];
       packed_load_chunk(v, al + c0, w.b, r);
-      mask |= (uint64_t)packed_eval_chunk<F>(v, w, sh, lo, hi, qaux, al + c0, r, keep, n) << c0;
+      mask |= (uint64_t)packed_eval_chunk<F>(v, w, lo, hi, qaux, al + c0, r, keep, n) << c0;
     }
   }
   return mask;
@@ -266,7 +267,7 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       uint64_t mask;
       if (packed) {
         const bool want = M == Mode::Count && keep != nullptr && qy.nseg == 1;
-        mask = light_mask_packed<F>(v, w, shf & 31u, lo, hi, qy.aux, al, want ? keep : nullptr);
+        mask = light_mask_packed<F>(v, w, lo, hi, qy.aux, al, want ? keep : nullptr);
         if (M == Mode::Count && rp) {
           rp->kept = want;
           rp->packed = true;
