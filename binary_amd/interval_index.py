@@ -183,9 +183,21 @@ class IntervalIndex:
     def query_workspace_bytes(self, q: int) -> int:
         return int(self._L.bivx_query_workspace_bytes(int(q)))
 
-    def query_device(self, qlow, qhigh, offsets, hits, workspace=None, qchrom=None, sort_by_id: bool = False):
-        """Single-pass count+prefix+fill into caller-owned buffers (bivx_query_dev); asynchronous.
-        offsets[-1] is the true hit total even if it exceeds hits.numel() (then only a prefix was written)."""
+    @staticmethod
+    def device_filter(kind: int, max_dist: int, use_strand: bool = True, query_aux=None, interval_aux=None):
+        """bivx_filter over DEVICE tensors (fused sv2nl check_condition, include/bivx.h). Keep the tensors alive."""
+        for name, t in (("query_aux", query_aux), ("interval_aux", interval_aux)):
+            if t is not None:
+                _check_dev_tensor(t, name)
+        return capi.Filter(kind, max_dist, 1 if use_strand else 0, 0,
+                           None if query_aux is None else query_aux.data_ptr(),
+                           None if interval_aux is None else interval_aux.data_ptr())
+
+    def query_device(self, qlow, qhigh, offsets, hits, workspace=None, qchrom=None, sort_by_id: bool = False,
+                     flt=None):
+        """Single-pass count+prefix+fill into caller-owned buffers (bivx_query_dev[_f]); asynchronous.
+        offsets[-1] is the true hit total even if it exceeds hits.numel() (then only a prefix was written).
+        flt: optional device_filter(...)."""
         self._ensure_built()
         q = qlow.numel()
         _check_dev_tensor(qlow, "qlow")
@@ -197,9 +209,10 @@ class IntervalIndex:
         if workspace is not None:
             _check_dev_tensor(workspace, "workspace", None, 1)
         s = C.c_void_p(torch.cuda.current_stream(qlow.device).cuda_stream)
-        capi.check(self._L.bivx_query_dev(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q, _tptr(offsets),
-                                          _tptr(hits), hits.numel(), _tptr(workspace),
-                                          0 if workspace is None else workspace.numel(), s))
+        capi.check(self._L.bivx_query_dev_f(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q,
+                                            None if flt is None else C.byref(flt), _tptr(offsets), _tptr(hits),
+                                            hits.numel(), _tptr(workspace),
+                                            0 if workspace is None else workspace.numel(), s))
         if sort_by_id:
             capi.check(self._L.bivx_sort_hits_dev(self._h, _tptr(offsets), _tptr(hits), q, s))
         return offsets, hits

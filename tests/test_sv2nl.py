@@ -151,6 +151,18 @@ def test_device_filters_equal_host_predicates_on_random_data():
             capi.check(L.bivx_count_f(idx._h, None, p(qlo), p(qhi), q, C.byref(flt), p(off)))
             hits = np.empty(int(off[-1]), np.uint32)
             capi.check(L.bivx_fill_f(idx._h, None, p(qlo), p(qhi), q, C.byref(flt), p(off), p(hits), 1))
+            # the single-pass kernel with the same filter (device pointers): same CSR, index order -> compare sorted
+            import torch
+            dev = torch.device("cuda:0")
+            to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+            t_qaux, t_iaux = to(qaux), to(iaux)
+            dflt = IntervalIndex.device_filter(kind, d, True, t_qaux, t_iaux)
+            d_off = torch.empty(q + 1, dtype=torch.int64, device=dev)
+            d_hits = torch.empty(max(int(off[-1]), 1), dtype=torch.int32, device=dev)
+            idx.query_device(to(qlo), to(qhi), d_off, d_hits, flt=dflt, sort_by_id=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), off), kind
+            assert np.array_equal(d_hits.cpu().numpy().view(np.uint32)[: int(off[-1])], hits), kind
         qid = np.repeat(np.arange(q), np.diff(off0.astype(np.int64)))
         a_lo, a_hi = qlo[qid].astype(np.int64), qhi[qid].astype(np.int64)
         b_lo, b_hi = lo_i[hits0].astype(np.int64), hi_i[hits0].astype(np.int64)
