@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <ostream>
 #include <ranges>
@@ -306,6 +307,9 @@ namespace binary::algorithm::tree {
 
     // uploads the intervals appended since the last query and (re)builds the device index
     void sync() const {
+      // const queries on a built tree may run concurrently (the reference relies on it, mapper.cpp:130-141): the
+      // lazy upload / build and the lazily replayed host tree are therefore serialised
+      std::lock_guard<std::mutex> lock(*lazy_);
       if (synced_ < items_.size()) {
         const std::size_t n = items_.size() - synced_;
         std::vector<std::uint32_t> lo(n), hi(n);
@@ -320,6 +324,7 @@ namespace binary::algorithm::tree {
     }
 
     auto shape() const -> Shape & {
+      std::lock_guard<std::mutex> lock(*lazy_);
       if (!shape_) {
         shape_ = std::make_unique<Shape>();
         preorder_rank_.clear();
@@ -337,6 +342,7 @@ namespace binary::algorithm::tree {
     // reorders insertion ids into the reference's pre-order (node, left, right)
     void rank_preorder(std::vector<std::uint32_t> &ids) const {
       Shape &s = shape();
+      std::lock_guard<std::mutex> lock(*lazy_);
       if (preorder_rank_.size() != items_.size()) {
         preorder_rank_.assign(items_.size(), 0);
         std::vector<std::pair<raw_pointer, std::uint32_t>> where;
@@ -362,6 +368,7 @@ namespace binary::algorithm::tree {
     std::unique_ptr<bivx_index, detail::IndexDeleter> index_;
     mutable std::size_t synced_{0};
     HitOrder order_{HitOrder::Insertion};
+    std::unique_ptr<std::mutex> lazy_{std::make_unique<std::mutex>()};  // (behind a pointer: the tree stays movable)
     mutable std::unique_ptr<Shape> shape_;
     mutable std::vector<raw_pointer> node_of_;
     mutable std::vector<std::uint32_t> preorder_rank_;

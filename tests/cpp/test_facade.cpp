@@ -12,6 +12,7 @@
 #include <filesystem>
 #include <random>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 using namespace binary::algorithm::tree;
@@ -229,6 +230,22 @@ static void gpu_cases() {
     CHECK(b.count(0) == 0 && b.count(1) == 2 && b.count(2) == 0 && b.count(3) == 2);
     CHECK(b.hits(1)[0] == 0 && b.hits(1)[1] == 1);
     CHECK_EQ(t.interval_at(1).tag, 9);
+  }
+  {  // concurrent const queries on one tree (TraMapper shares a tree across pool threads, mapper.cpp:130-141)
+    IntervalTree<UIntIntervalNode> t{};
+    for (std::uint32_t i = 0; i < 20000; ++i) t.insert_node(i * 7u, i * 7u + 20u);
+    std::vector<std::size_t> got(8, 0);
+    std::vector<std::thread> pool;
+    for (int w = 0; w < 8; ++w)
+      pool.emplace_back([&, w] {
+        for (std::uint32_t k = 0; k < 40; ++k) got[w] += t.find_overlaps(1000u * (k + 1) + w, 1000u * (k + 1) + w + 30u).size();
+        if (w == 0) got[w] += t.root() != nullptr ? 0 : 1;  // the lazy host tree under contention too
+      });
+    for (auto &th : pool) th.join();
+    std::size_t expect0 = 0;
+    for (std::uint32_t k = 0; k < 40; ++k) expect0 += t.find_overlaps(1000u * (k + 1), 1000u * (k + 1) + 30u).size();
+    CHECK_EQ(got[0], expect0);
+    for (int w = 1; w < 8; ++w) CHECK(got[w] >= expect0 - 40 && got[w] <= expect0 + 40);
   }
   {  // empty tree
     IntervalTree<UIntIntervalNode> t{};

@@ -16,7 +16,7 @@ def facade_binary(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("facade") / "test_facade")
     libdir = os.path.join(ROOT, "binary_amd")
     cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "test_facade.cpp"), "-o", out, "-L", libdir, "-lbivx",
+           os.path.join(ROOT, "tests", "cpp", "test_facade.cpp"), "-o", out, "-L", libdir, "-lbivx", "-pthread",
            f"-Wl,-rpath,{libdir}"]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     return out
