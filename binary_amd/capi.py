@@ -10,7 +10,7 @@ import os
 from ._build import LIB_PATH
 
 BIVX_NO_HIT = 0xFFFFFFFF
-ABI_VERSION = 0x00010000
+ABI_VERSION = 0x00010001
 
 EXPORTS = (
     "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_destroy", "bivx_device", "bivx_append",
@@ -39,7 +39,7 @@ class Filter(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_intervals", C.c_uint64), ("n_chroms", C.c_uint32), ("n_segments", C.c_uint32),
                 ("n_cells", C.c_uint64), ("index_bytes", C.c_uint64), ("staging_bytes", C.c_uint64),
-                ("build_ms", C.c_double)]
+                ("build_ms", C.c_double), ("prefix_timeouts", C.c_uint64)]
 
 
 _lib = None

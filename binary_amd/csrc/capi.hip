@@ -801,6 +801,17 @@ int bivx_get_stats(const bivx_index *idx, bivx_stats *out) {
     out->index_bytes = (uint64_t)idx->built_n * 20 + idx->nentries * 4 + (uint64_t)idx->nseg * sizeof(SegDesc) +
                        ((uint64_t)idx->nchrom + 1) * 4;
   out->build_ms = idx->build_ms;
+  {  // bounded prefix waits of the single-pass kernel that gave up (index-owned workspaces): expected to stay 0
+    BIVX_GUARD(idx);
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    for (auto &kv : idx->ws_of_stream) {
+      uint32_t t = 0;
+      BIVX_HIP(hipDeviceSynchronize());
+      BIVX_HIP(hipMemcpy(&t, static_cast<const uint8_t *>(kv.second) + fused_workspace_timeouts_offset(), 4,
+                         hipMemcpyDeviceToHost));
+      out->prefix_timeouts += t;
+    }
+  }
   return 0;
 }
 

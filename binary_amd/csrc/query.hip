@@ -421,7 +421,7 @@ constexpr uint32_t kStageMin = 320;  // ... when it has at least this many (5 pe
 constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
 // on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
-constexpr uint32_t kWsTicket = 0, kWsDone = 16, kWsStatus = 32;
+constexpr uint32_t kWsTicket = 0, kWsDone = 16, kWsTimeouts = 24, kWsStatus = 32;  // kWsTimeouts is never cleared by the kernel
 constexpr uint32_t kSpinCap = 1u << 20;
 
 __device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
@@ -782,6 +782,8 @@ size_t fused_workspace_bytes(size_t q) {
   (void)q;
   return ((size_t)kFMaxTiles + kWsStatus) * sizeof(uint64_t);
 }
+
+size_t fused_workspace_timeouts_offset() { return (size_t)kWsTimeouts * sizeof(uint64_t); }
 
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,

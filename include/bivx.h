@@ -47,7 +47,7 @@ typedef enum bivx_status {
 #define BIVX_NO_HIT 0xFFFFFFFFu
 
 /* ABI version of this header: major << 16 | minor. */
-#define BIVX_ABI_VERSION 0x00010000u
+#define BIVX_ABI_VERSION 0x00010001u
 uint32_t bivx_abi_version(void);
 const char *bivx_last_error(void);
 
@@ -183,6 +183,9 @@ typedef struct bivx_stats {
   uint64_t index_bytes;     /* device bytes of the built index (sorted arrays + directory) */
   uint64_t staging_bytes;   /* device bytes of the append-order copy */
   double build_ms;          /* wall time of the last bivx_build */
+  uint64_t prefix_timeouts; /* bounded cross-workgroup waits of bivx_query_dev (index-owned workspace) that gave up since
+                               the last build; 0 unless the device stopped making progress — results of such a call
+                               are invalid. Reading it synchronises the device. */
 } bivx_stats;
 int bivx_get_stats(const bivx_index *idx, bivx_stats *out);
 

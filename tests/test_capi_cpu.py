@@ -33,7 +33,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.bivx_abi_version() == 0x00010000
+    assert lib.bivx_abi_version() == 0x00010001
 
 
 def test_code_object_is_gfx950(lib):
@@ -67,3 +67,31 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".c")):
                     text = open(os.path.join(dp, f), errors="replace").read()
                     assert "oracle" not in text.lower() or f in (), f"{dp}/{f} mentions the oracle"
+
+
+@pytest.fixture(scope="module")
+def c_example(tmp_path_factory):
+    """include/bivx.h is a C header: a C11 program (no C++) must compile against it and link libbivx.so."""
+    from binary_amd import _build
+    _build.build_lib()
+    out = str(tmp_path_factory.mktemp("cabi") / "capi_example")
+    libdir = os.path.join(ROOT, "binary_amd")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "capi_example.c"), "-o", out, "-L", libdir, "-lbivx",
+                    f"-Wl,-rpath,{libdir}"], check=True, capture_output=True, text=True)
+    return out
+
+
+def test_header_is_plain_c_and_program_links(c_example):
+    import torch
+    r = subprocess.run([c_example], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "no GPU" in r.stdout  # fails loudly, no fallback
+
+
+@pytest.mark.gpu
+def test_c_program_reference_fixture_on_gpu(c_example):
+    r = subprocess.run([c_example], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "capi_example: ok" in r.stdout, r.stdout + r.stderr

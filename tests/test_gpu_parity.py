@@ -363,9 +363,44 @@ def test_single_pass_index_owned_workspace(IntervalIndex):
                     stream.synchronize()
                 assert np.array_equal(off.cpu().numpy().astype(np.uint64), ref_off)
                 assert np.array_equal(hits.cpu().numpy().view(np.uint32)[: int(ref_off[-1])], ref_hits)
+            assert idx.stats()["prefix_timeouts"] == 0  # no cross-workgroup wait ever gave up
             if rep == 2:
                 idx.insert_node(low[:1000], high[:1000])  # forces a rebuild; workspaces are reset with it
                 idx.build()
+
+
+def test_single_pass_under_hip_graph_capture(IntervalIndex):
+    """The device entry points allocate nothing and never synchronise once their buffers exist, so a step can be
+    captured into a HIP graph and replayed (torch.cuda.CUDAGraph is a hipGraph on ROCm)."""
+    import torch
+    from binary_amd import synth
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    low, high = synth.gen_intervals(200_000, 20_000_000, 1000)
+    qlo, qhi = synth.gen_range_queries(100_000, 20_000_000, 1000)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        ref_off, ref_hits = idx.find_overlaps(qlo, qhi, sort_by_id=True)
+        d_qlo, d_qhi = to(qlo), to(qhi)
+        off = torch.zeros(qlo.size + 1, dtype=torch.int64, device=dev)
+        hits = torch.zeros(int(ref_off[-1]), dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(3):  # warm up on the capture stream: creates the index-owned workspace of that stream
+                idx.query_device(d_qlo, d_qhi, off, hits, sort_by_id=True)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            idx.query_device(d_qlo, d_qhi, off, hits, sort_by_id=True)
+        for _ in range(3):
+            off.zero_()
+            hits.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), ref_off)
+            assert np.array_equal(hits.cpu().numpy().view(np.uint32), ref_hits)
+        assert idx.stats()["prefix_timeouts"] == 0
 
 
 def test_single_pass_repeated_calls_are_deterministic(IntervalIndex):
