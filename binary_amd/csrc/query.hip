@@ -24,6 +24,10 @@ namespace {
 constexpr int kQThreads = 256;
 constexpr int kQWaves = kQThreads / kWave;
 constexpr uint32_t kLight = 64;      // window slots a lane reads by itself; longer windows go to the wavefront
+#ifndef BIVX_TRIM
+#define BIVX_TRIM 512
+#endif
+constexpr uint32_t kTrim = BIVX_TRIM;  // wavefront windows longer than this are first trimmed by a 64-ary search
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
 constexpr uint32_t kLdsChroms = 511; // ... with chrom_seg (2 KiB); larger indexes read them from global
 
@@ -206,6 +210,28 @@ __device__ __forceinline__ uint64_t light_mask_packed(const IndexView &v, const 
   return mask;
 }
 
+// First slot in [a, b) whose low is >= x (b if there is none), found by the whole wavefront: a 64-ary search — the
+// 64 lanes probe 64 evenly spaced slots, one __ballot tells which gap holds the answer, repeat. Used to trim long
+// candidate windows (many intervals starting inside one directory cell) to the slots whose low lies in
+// [q.low - maxlen, q.high] before they are scanned. All 64 lanes must call it with the same arguments.
+__device__ __forceinline__ uint32_t wave_lower_bound_low(const uint2 *se, uint32_t a, uint32_t b, uint32_t x, int lane) {
+  while (b - a > (uint32_t)kWave) {
+    const uint32_t step = (b - a + kWave - 1) / kWave;
+    const uint32_t p = a + step * (uint32_t)lane;
+    const bool ge = p < b ? se[p].x >= x : true;  // lows ascend inside a segment: the ballot is 0..01..1
+    const uint64_t m = __ballot(ge);
+    const uint32_t first = m ? (uint32_t)__ffsll((long long)m) - 1u : (uint32_t)kWave;
+    const uint32_t nb = first < (uint32_t)kWave ? min(a + step * first, b) : b;
+    const uint32_t na = first > 0 ? a + step * (first - 1) + 1 : a;
+    a = na;
+    b = nb;
+  }
+  const uint32_t p = a + (uint32_t)lane;
+  const uint64_t m = __ballot(p < b ? se[p].x >= x : true);
+  const uint32_t first = m ? (uint32_t)__ffsll((long long)m) - 1u : (uint32_t)kWave;
+  return min(a + first, b);
+}
+
 // orders one wavefront's LDS / global accesses: what lanes wrote before is visible to all lanes after
 __device__ __forceinline__ void wave_sync_mem() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -253,11 +279,12 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
   // the segment loop is wavefront-uniform so the cooperative part may use __ballot / __shfl
   for (uint32_t k = 0; __any(k < qy.nseg); ++k) {
     Window w{0u, 0u, 0u, 0u, false};
-    uint32_t shf = 0;
+    uint32_t shf = 0, xlow = 0;
     if (k < qy.nseg) {
       const SegDesc d = load_seg(segs + qy.s0 + k);
       w = seg_window(v, d, lo, hi);
       shf = d.shift;
+      xlow = lo > d.maxlen ? lo - d.maxlen : 0u;
     }
     const bool nonempty = w.span != 0 && w.b > w.a;
     const bool packed = (shf & kSegPacked) != 0 && w.narrow;
@@ -299,9 +326,13 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
     while (hm) {
       const int src = __ffsll((long long)hm) - 1;
       hm &= hm - 1;
-      const uint32_t ca = __shfl(w.a, src, kWave), cb = __shfl(w.b, src, kWave);
+      uint32_t ca = __shfl(w.a, src, kWave), cb = __shfl(w.b, src, kWave);
       const uint32_t cl = __shfl(lo, src, kWave), ch = __shfl(hi, src, kWave);
       const uint32_t cx = F ? __shfl(qy.aux, src, kWave) : 0u;
+      if (cb - ca > kTrim) {  // long window: trim it to the slots with low in [q.low - maxlen, q.high]
+        ca = wave_lower_bound_low(v.se, ca, cb, __shfl(xlow, src, kWave), lane);
+        if (ch != 0xFFFFFFFFu) cb = wave_lower_bound_low(v.se, ca, cb, ch + 1u, lane);
+      }
       auto is_hit = [&](uint32_t j) {
         const uint2 e = v.se[j];
         return e.x <= ch && e.y >= cl &&

@@ -420,3 +420,31 @@ def test_single_pass_repeated_calls_are_deterministic(IntervalIndex):
             if ref is None:
                 ref = cur
             assert np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1])
+
+
+def test_clustered_intervals_long_cells_are_trimmed(IntervalIndex, oracle):
+    """Positional hotspots: hundreds of thousands of intervals start inside a few directory cells, so directory
+    windows are long and the wavefront path trims them with its 64-ary search before scanning."""
+    rng = np.random.default_rng(33)
+    hot = rng.integers(5_000_000, 5_020_000, size=300_000).astype(np.uint32)          # 20 kbp hotspot
+    hot2 = rng.integers(90_000_000, 90_000_400, size=50_000).astype(np.uint32)        # 400 bp hotspot
+    bg = rng.integers(0, 200_000_000, size=50_000).astype(np.uint32)
+    low = np.concatenate([hot, hot2, bg])
+    high = low + rng.integers(0, 300, size=low.size).astype(np.uint32)
+    perm = rng.permutation(low.size)
+    low, high = low[perm], high[perm]
+    qlo = np.concatenate([rng.integers(4_999_000, 5_021_000, size=3000), rng.integers(89_999_900, 90_000_500, size=1000),
+                          rng.integers(0, 200_000_000, size=2000)]).astype(np.uint32)
+    qhi = qlo + rng.integers(0, 50, size=qlo.size).astype(np.uint32)
+    qhi[:5] = qlo[:5] + 15_000   # a few long ones across the hotspot
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        off, hits = idx.find_overlaps(qlo, qhi)
+        first = idx.find_overlap(qlo, qhi)
+    off_o, hits_o = oracle_csr_sorted(oracle, low, high, qlo, qhi)
+    assert np.array_equal(off, off_o) and np.array_equal(hits.astype(np.int64), hits_o)
+    cnt = np.diff(off_o.astype(np.int64))
+    assert cnt.max() > 50_000
+    exp_first = np.where(cnt > 0, hits_o[np.minimum(off_o[:-1].astype(np.int64), hits_o.size - 1)], M32)
+    assert np.array_equal(first.astype(np.int64), exp_first)
