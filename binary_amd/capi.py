@@ -18,6 +18,7 @@ EXPORTS = (
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_workspace_bytes", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
     "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f",
+    "bivx_find_overlaps", "bivx_free",
 )
 
 
@@ -85,6 +86,9 @@ def load() -> C.CDLL:
     L.bivx_any_dev.argtypes = [vp, u32p, u32p, u32p, sz, u32p, vp]
     L.bivx_get_stats.argtypes = [vp, C.POINTER(Stats)]
     fp = C.POINTER(Filter)
+    L.bivx_find_overlaps.argtypes = [vp, u32p, u32p, u32p, sz, fp, C.c_int, u64p, C.POINTER(C.POINTER(C.c_uint32))]
+    L.bivx_free.argtypes = [vp]
+    L.bivx_free.restype = None
     L.bivx_count_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p]
     L.bivx_fill_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, C.c_int]
     L.bivx_count_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, vp, sz, vp]

@@ -765,6 +765,59 @@ int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *q
   return 0;
 }
 
+int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                       size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+                       uint32_t **hit_ids_out) {
+  BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_find_overlaps"));
+  if (!offsets_out || !hit_ids_out) {
+    set_error("bivx_find_overlaps: null output");
+    return BIVX_E_INVALID;
+  }
+  *hit_ids_out = nullptr;
+  if (q == 0) {
+    offsets_out[0] = 0;
+    return 0;
+  }
+  BIVX_GUARD(idx);
+  hipStream_t s = idx->stream;
+  TempPool tmp;
+  DevQueries d;
+  BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
+  bivx_filter dflt;
+  BIVX_TRY(upload_filter(tmp, idx, filter, q, s, dflt));
+  uint64_t *d_off = nullptr;
+  uint8_t *d_ws = nullptr;
+  const size_t wsb = bivx_count_workspace_bytes(q);
+  BIVX_TRY(tmp.alloc(&d_off, q + 1));
+  BIVX_TRY(tmp.alloc(&d_ws, wsb));
+  BIVX_TRY(bivx_count_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, d_ws, wsb, s));
+  uint64_t total = 0;
+  BIVX_HIP(hipMemcpyAsync(&total, d_off + q, 8, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipMemcpyAsync(offsets_out, d_off, (q + 1) * 8, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  if (total == 0) return 0;
+  uint32_t *h = static_cast<uint32_t *>(std::malloc((size_t)total * sizeof(uint32_t)));
+  if (!h) {
+    set_error("bivx_find_overlaps: out of host memory for %llu hit ids", (unsigned long long)total);
+    return BIVX_E_NOMEM;
+  }
+  uint32_t *d_hits = nullptr;
+  int rc = tmp.alloc(&d_hits, (size_t)total);
+  if (rc == 0) rc = bivx_fill_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, d_hits, s);
+  if (rc == 0 && sort_by_id) rc = bivx_sort_hits_dev(idx, d_off, d_hits, q, s);
+  if (rc == 0 && hipMemcpyAsync(h, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost, s) != hipSuccess) rc = BIVX_E_HIP;
+  if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = BIVX_E_HIP;
+  if (rc != 0) {
+    if (rc == BIVX_E_HIP) set_error("bivx_find_overlaps: device copy failed");
+    std::free(h);
+    return rc;
+  }
+  *hit_ids_out = h;
+  return 0;
+}
+
+void bivx_free(void *p) { std::free(p); }
+
 int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
              uint32_t *first_id_out) {
   BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_any"));

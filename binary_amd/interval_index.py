@@ -9,6 +9,7 @@ streams; every result comes from the hand-written HIP kernels in libbivx.so. No 
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -132,11 +133,18 @@ class IntervalIndex:
         qc = None if qchrom is None else _u32(qchrom).ravel()
         q = qlow.size
         offsets = np.zeros(q + 1, dtype=np.uint64)
-        capi.check(self._L.bivx_count(self._h, _ptr(qc), _ptr(qlow), _ptr(qhigh), q, _ptr(offsets)))
-        hits = np.empty(int(offsets[-1]), dtype=np.uint32)
-        capi.check(self._L.bivx_fill(self._h, _ptr(qc), _ptr(qlow), _ptr(qhigh), q, _ptr(offsets), _ptr(hits),
-                                     1 if sort_by_id else 0))
-        return offsets, hits
+        hp = C.POINTER(C.c_uint32)()
+        capi.check(self._L.bivx_find_overlaps(self._h, _ptr(qc), _ptr(qlow), _ptr(qhigh), q, None,
+                                              1 if sort_by_id else 0, _ptr(offsets), C.byref(hp)))
+        total = int(offsets[-1])
+        if total == 0:
+            return offsets, np.zeros(0, dtype=np.uint32)
+        # a zero-copy view of the library's buffer: the ctypes array is the numpy base of `hits` and of every view
+        # taken from it, and bivx_free runs when the last of them is gone
+        addr = C.cast(hp, C.c_void_p).value
+        buf = (C.c_uint32 * total).from_address(addr)
+        weakref.finalize(buf, self._L.bivx_free, C.c_void_p(addr))
+        return offsets, np.ctypeslib.as_array(buf)
 
     def find_overlap(self, qlow, qhigh, qchrom=None) -> np.ndarray:
         """Per query the smallest overlapping id, or capi.BIVX_NO_HIT (find_overlap, interval_tree.hpp:290-304)."""

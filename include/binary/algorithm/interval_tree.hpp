@@ -262,10 +262,12 @@ namespace binary::algorithm::tree {
       OverlapBatch b;
       const std::size_t q = low_u32.size();
       b.offsets.assign(q + 1, 0);
-      detail::check(bivx_count(index_.get(), nullptr, low_u32.data(), high_u32.data(), q, b.offsets.data()), "bivx_count");
-      b.ids.resize(static_cast<std::size_t>(b.offsets[q]));
-      detail::check(bivx_fill(index_.get(), nullptr, low_u32.data(), high_u32.data(), q, b.offsets.data(), b.ids.data(), 1),
-                    "bivx_fill");
+      std::uint32_t *ids = nullptr;
+      detail::check(bivx_find_overlaps(index_.get(), nullptr, low_u32.data(), high_u32.data(), q, nullptr, 1,
+                                       b.offsets.data(), &ids),
+                    "bivx_find_overlaps");
+      if (ids != nullptr) b.ids.assign(ids, ids + b.offsets[q]);
+      bivx_free(ids);
       return b;
     }
 

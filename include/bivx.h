@@ -33,6 +33,7 @@ extern "C" {
 #endif
 
 typedef struct bivx_index bivx_index;
+typedef struct bivx_filter bivx_filter; /* fused post-filter, defined below */
 
 typedef enum bivx_status {
   BIVX_OK = 0,
@@ -99,6 +100,14 @@ int bivx_count(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *ql
 int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
               size_t q, const uint64_t *offsets, uint32_t *hit_ids_out, int sort_by_id);
 
+/* One call for host callers: uploads the queries once, counts, sizes the result, enumerates (ids ascending inside each
+ * query when sort_by_id != 0) and downloads. *hit_ids_out is allocated by the library (NULL when there is no hit);
+ * release it with bivx_free. `filter` may be NULL. */
+int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                       size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+                       uint32_t **hit_ids_out);
+void bivx_free(void *p);
+
 /* device-resident variants. d_workspace: bivx_count_workspace_bytes(q) bytes of scratch (NULL => the call
  * allocates and frees stream-ordered scratch itself). */
 size_t bivx_count_workspace_bytes(size_t q);
@@ -149,14 +158,14 @@ int bivx_any_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t
  * query_aux has one word per query, interval_aux one word per interval in append order; host pointers for the
  * host entry points, device pointers for the _dev ones; either may be NULL when the kind does not read it. */
 enum { BIVX_FILTER_NONE = 0, BIVX_FILTER_SV2NL_DUP = 1, BIVX_FILTER_SV2NL_INV = 2, BIVX_FILTER_SV2NL_TRA = 3 };
-typedef struct bivx_filter {
+struct bivx_filter {
   uint32_t kind;
   uint32_t max_dist;   /* sv2nl --dis */
   uint32_t use_strand; /* sv2nl: !--short */
   uint32_t reserved;
   const uint32_t *query_aux;
   const uint32_t *interval_aux;
-} bivx_filter;
+};
 
 /* the filtered forms of count / fill / query; filter == NULL or kind == BIVX_FILTER_NONE gives the plain calls */
 int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,

@@ -11,7 +11,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-extra = " ".join(sys.argv[1:])
+SORTED = "--sorted" in sys.argv
+extra = " ".join(a for a in sys.argv[1:] if a != "--sorted")
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "clean"])
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "-j8", f"EXTRA=-DBIVX_STAMPS {extra}"])
 from binary_amd import IntervalIndex, synth, capi  # noqa: E402
@@ -20,6 +21,9 @@ dev = torch.device("cuda:0")
 L = int(synth.HG38_LENGTHS[0])
 lo, hi = synth.gen_intervals(1_000_000, L, 1000, 0)
 ql, qh = synth.gen_point_queries(1_000_000, L, 0)
+if SORTED:
+    ql = np.sort(ql)
+    qh = ql.copy()
 to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
 idx = IntervalIndex(0)
 idx.insert_node(lo, hi)
