@@ -56,7 +56,12 @@ struct bivx_index {
 
 namespace {
 
-constexpr double kSearchCost = 16.0;  // cost of one extra segment search, in scanned-candidate units
+// cost of one extra segment search, in scanned-candidate units (BIVX_SEARCH_COST overrides: tuning knob)
+static const double kSearchCost = [] {
+  const char *e = std::getenv("BIVX_SEARCH_COST");
+  const double v = e ? std::atof(e) : 16.0;
+  return v > 0.0 ? v : 16.0;
+}();
 
 struct DeviceGuard {
   int prev = -1;
