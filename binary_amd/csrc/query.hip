@@ -6,11 +6,12 @@
 // holding q.high. Every candidate is then tested with the reference predicate low <= q.high &&
 // q.low <= high; no binary search is needed because slots outside [x, q.high] fail the predicate by
 // themselves. All candidate loads are independent of each other (16-byte loads, several in flight).
-//   - packed segments: 8-byte records (16-bit offset in cell | 16-bit length, id), two per load: the line that
-//     says "hit" also carries the id
+//   - packed segments: 8-byte records (low's 16 low bits | 16-bit length, id), two per load: the line that says
+//     "hit" also carries the id
 //   - other segments:  8-byte (low, high) pairs, two per load; ids in a parallel array
 //   - windows longer than kLight slots are read by the whole wavefront (coalesced rows, __ballot compaction),
-//     so a chromosome-scale query costs O(window / 64) wave steps instead of stalling one lane
+//     so a chromosome-scale query costs O(window / 64) wave steps instead of stalling one lane; very long
+//     ones are first trimmed by a wavefront 64-ary search (__ballot picks the gap)
 // Segment descriptors are staged through LDS. Integer compare/index work only: no MFMA anywhere.
 //
 // Two ways in:  k_query<Count|Fill|Any>  (two-pass API: count -> offsets scan -> fill), and
