@@ -1,0 +1,80 @@
+"""Medium-size randomized differential test against the tree oracle: every case mixes what the small property test
+cannot reach at once — several chromosomes, several length classes per chromosome, positional hotspots (long
+directory cells, the trimmed wavefront path), long queries (hit lists in every sort tier), inverted intervals, and
+query counts that are not multiples of the tile sizes — and checks two-pass, single-pass and existence."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    nchrom = int(rng.integers(1, 6))
+    n = int(rng.integers(1_000, 120_000))
+    q = int(rng.integers(1, 40_000))
+    L = int(rng.choice([50_000, 5_000_000, 400_000_000, 0xFFFF0000]))
+    chrom = rng.integers(0, nchrom, size=n).astype(np.uint32)
+    low = rng.integers(0, L, size=n).astype(np.uint64)
+    if rng.random() < 0.5:  # hotspots
+        k = int(n * rng.uniform(0.2, 0.8))
+        centre = rng.integers(0, L, size=3)
+        low[:k] = centre[rng.integers(0, 3, size=k)] + rng.integers(0, max(1, L // 5000), size=k)
+    kinds = rng.choice(4, size=n, p=[0.6, 0.25, 0.1, 0.05])
+    ln = np.where(kinds == 0, rng.integers(0, 500, size=n),
+         np.where(kinds == 1, rng.integers(500, 70_000, size=n),
+         np.where(kinds == 2, rng.integers(70_000, max(70_001, L // 3), size=n), 0))).astype(np.uint64)
+    high = np.minimum(low + ln, 0xFFFFFFFF)
+    low, high = low.astype(np.uint32), high.astype(np.uint32)
+    inv = rng.random(n) < 0.03
+    low, high = np.where(inv, high, low).astype(np.uint32), np.where(inv, low, high).astype(np.uint32)
+    qchrom = rng.integers(0, nchrom + 1, size=q).astype(np.uint32)
+    qlo = rng.integers(0, L, size=q).astype(np.uint64)
+    qln = np.where(rng.random(q) < 0.9, rng.integers(0, 300, size=q), rng.integers(0, max(1, L // 2), size=q)).astype(np.uint64)
+    qhi = np.minimum(qlo + qln, 0xFFFFFFFF)
+    return chrom, low, high, qchrom, qlo.astype(np.uint32), qhi.astype(np.uint32), nchrom
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("BIVX_FUZZ_CASES", "12")))))
+def test_fuzz_against_tree_oracle(seed, oracle):
+    import torch
+    from binary_amd import IntervalIndex
+    chrom, low, high, qchrom, qlo, qhi, nchrom = make_case(1000 + seed)
+    # oracle: one tree per chromosome
+    q = qlo.size
+    exp_cnt = np.zeros(q, np.int64)
+    exp_lists = [None] * q
+    for c in range(nchrom + 1):
+        qi = np.nonzero(qchrom == c)[0]
+        ii = np.nonzero(chrom == c)[0]
+        if qi.size == 0:
+            continue
+        if ii.size == 0:
+            for k in qi:
+                exp_lists[k] = np.zeros(0, np.int64)
+            continue
+        t = oracle.OracleTree(low[ii], high[ii])
+        off_o, hits_o = t.find_overlaps_batch(qlo[qi], qhi[qi], nthreads=4)
+        srt = oracle.sorted_csr(off_o, hits_o)
+        for j, k in enumerate(qi):
+            exp_lists[k] = ii[srt[int(off_o[j]):int(off_o[j + 1])]]
+            exp_cnt[k] = exp_lists[k].size
+    exp_off = np.concatenate([[0], np.cumsum(exp_cnt)]).astype(np.uint64)
+    exp_hits = np.concatenate(exp_lists).astype(np.uint32) if exp_off[-1] else np.zeros(0, np.uint32)
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high, chrom)
+        idx.build()
+        off, hits = idx.find_overlaps(qlo, qhi, qchrom, sort_by_id=True)
+        assert np.array_equal(off, exp_off), f"seed {seed}: counts (segments {idx.stats()['n_segments']})"
+        assert np.array_equal(hits, exp_hits), f"seed {seed}: hit ids"
+        first = idx.find_overlap(qlo, qhi, qchrom)
+        assert np.array_equal(first, np.array([l[0] if l.size else 0xFFFFFFFF for l in exp_lists], dtype=np.uint32))
+        d_off = torch.empty(q + 1, dtype=torch.int64, device=dev)
+        d_hits = torch.empty(max(int(exp_off[-1]), 1), dtype=torch.int32, device=dev)
+        idx.query_device(to(qlo), to(qhi), d_off, d_hits, qchrom=to(qchrom), sort_by_id=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), exp_off)
+        assert np.array_equal(d_hits.cpu().numpy().view(np.uint32)[: int(exp_off[-1])], exp_hits)
+        assert idx.stats()["prefix_timeouts"] == 0
