@@ -606,6 +606,13 @@ int bivx_query_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32
 int bivx_query_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                      size_t q, const bivx_filter *filter, uint64_t *d_offsets, uint32_t *d_hit_ids,
                      uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes, void *stream) {
+  return bivx_query_dev_s(idx, d_qchrom, d_qlow, d_qhigh, q, filter, 0, d_offsets, d_hit_ids, hit_capacity, d_workspace,
+                          workspace_bytes, stream);
+}
+
+int bivx_query_dev_s(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                     size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *d_offsets, uint32_t *d_hit_ids,
+                     uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes, void *stream) {
   BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_query_dev"));
   IndexView view;
   BIVX_TRY(view_with_filter(idx, filter, view));
@@ -633,7 +640,7 @@ int bivx_query_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint
     self_clean = true;
   }
   return launch_query_fused(view, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, hit_capacity, d_workspace,
-                            self_clean, s);
+                            self_clean, sort_by_id != 0, s);
 }
 
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q, void *stream) {
@@ -642,7 +649,7 @@ int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
-  return launch_sort_hits(d_offsets, d_hit_ids, q, static_cast<hipStream_t>(stream));
+  return launch_sort_hits(d_offsets, d_hit_ids, q, ~0ull, static_cast<hipStream_t>(stream));
 }
 
 int bivx_any_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,

@@ -107,12 +107,12 @@ int launch_fill(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_
                 size_t q, const uint64_t *d_offsets, uint32_t *d_hits, hipStream_t s);
 int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                size_t q, uint32_t *d_first, hipStream_t s);
-int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, hipStream_t s);
+int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, uint64_t cap, hipStream_t s);
 // single pass: offsets[q+1] and hits (slots below cap only) in one kernel; ws: fused_workspace_bytes(q)
 size_t fused_workspace_bytes(size_t q);
 size_t fused_workspace_timeouts_offset();  // byte offset of the "prefix wait gave up" counter inside a workspace
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
-                       void *d_ws, bool self_clean, hipStream_t s);
+                       void *d_ws, bool self_clean, bool sort_ids, hipStream_t s);
 
 }  // namespace bivx

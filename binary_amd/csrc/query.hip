@@ -427,6 +427,147 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
   if (valid && M != Mode::Fill) out[q] = r;
 }
 
+// ---- per-query ascending-id ordering of a CSR hit list ------------------------------------------------
+
+constexpr uint32_t kRankMax = 48;     // lists up to this long are rank-sorted by their lane (fast path)
+constexpr uint32_t kRankBlock = 8;   // elements ranked per sweep of a list (held in registers)
+#ifndef BIVX_FUSED_RANK_BLOCK
+#define BIVX_FUSED_RANK_BLOCK 8
+#endif
+constexpr uint32_t kFusedSortMaxAvg = 6;   // ids per query (by buffer capacity) up to which k_query_fused orders ids itself
+constexpr uint32_t kFusedRankBlock = BIVX_FUSED_RANK_BLOCK;  // the same inside k_query_fused, which lives in 64 VGPRs
+constexpr uint32_t kSortLane = 24;    // <= this many hits: the owning lane insertion-sorts in place
+constexpr uint32_t kSortLds = 4096;   // <= this many: the wavefront bitonic-sorts through LDS (16 KiB per wavefront)
+
+// Ascending sort of s[0..n) by one wavefront: the normalised bitonic network (every comparator puts the
+// minimum at the lower index), so virtual +inf pads at indices >= n never move and comparators that
+// touch them are simply skipped — any n sorts in place, in LDS or in global memory.
+template <typename IdxT>
+__device__ __forceinline__ void wave_bitonic_sort(uint32_t *s, IdxT n, int lane) {
+  IdxT np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (IdxT k = 2; k <= np2; k <<= 1) {
+    for (IdxT t = lane; t < n; t += kWave) {
+      const IdxT p = t ^ (k - 1);
+      if (p > t && p < n) {
+        const uint32_t x = s[t], y = s[p];
+        if (x > y) {
+          s[t] = y;
+          s[p] = x;
+        }
+      }
+    }
+    wave_sync_mem();
+    for (IdxT j = k >> 2; j > 0; j >>= 1) {
+      for (IdxT t = lane; t < n; t += kWave) {
+        const IdxT p = t ^ j;
+        if (p > t && p < n) {
+          const uint32_t x = s[t], y = s[p];
+          if (x > y) {
+            s[t] = y;
+            s[p] = x;
+          }
+        }
+      }
+      wave_sync_mem();
+    }
+  }
+}
+
+// One lane's list in[off .. off + n) rank-sorted into outb[off ..): rank = how many elements are smaller (ids
+// are distinct inside a query). kRankBlock elements are ranked per sweep of the list, so a list costs
+// n * ceil(n / kRankBlock) independent LDS reads — no dependent chain, unlike an insertion sort, and an eighth
+// of the n^2 reads of the plain form (LDS bandwidth is what bounds this when lists are ~16 long).
+template <uint32_t kRankBlock>
+__device__ __forceinline__ void rank_sort_list(const uint32_t *in, uint32_t *outb, uint32_t off, uint32_t n) {
+  for (uint32_t i0 = 0; i0 < n; i0 += kRankBlock) {
+    uint32_t x[kRankBlock], rank[kRankBlock];
+#pragma unroll
+    for (uint32_t k = 0; k < kRankBlock; ++k) {
+      x[k] = i0 + k < n ? in[off + i0 + k] : 0u;
+      rank[k] = 0;
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+      const uint32_t y = in[off + j];
+#pragma unroll
+      for (uint32_t k = 0; k < kRankBlock; ++k) rank[k] += y < x[k] ? 1u : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kRankBlock; ++k)
+      if (i0 + k < n) outb[off + rank[k]] = x[k];
+  }
+}
+
+// Sorts the 64 hit lists of one wavefront, hits[o0 .. o1) per lane (adjacent in memory, lane order), ascending,
+// in place. `lds` is the wavefront's own stage of LDSN words. All 64 lanes must call it.
+template <uint32_t LDSN, uint32_t RB>
+__device__ __forceinline__ void wave_sort_lists(uint32_t *lds, uint64_t o0, uint64_t o1, uint32_t *hits, int lane) {
+  const uint64_t cnt = o1 - o0;
+  // Fast path, the usual case: every list of the wavefront is short and the 64 lists fit half the stage. The
+  // region is loaded with coalesced reads, every lane rank-sorts its own list out of LDS into the other half,
+  // which is streamed back coalesced.
+  const uint64_t wb = __shfl((unsigned long long)o0, 0, kWave);
+  const uint64_t we = __shfl((unsigned long long)o1, kWave - 1, kWave);
+  if (__all(cnt <= kRankMax) && we - wb <= LDSN / 2) {
+    const uint32_t wtotal = (uint32_t)(we - wb);
+    uint32_t *in = lds, *outb = lds + LDSN / 2;
+    if (__any(cnt > 1)) {
+      for (uint32_t i = lane; i < wtotal; i += kWave) in[i] = hits[wb + i];
+      wave_sync_mem();
+      rank_sort_list<RB>(in, outb, (uint32_t)(o0 - wb), (uint32_t)cnt);
+      wave_sync_mem();
+      for (uint32_t i = lane; i < wtotal; i += kWave) hits[wb + i] = outb[i];
+      wave_sync_mem();
+    }
+    return;
+  }
+  if (cnt > 1 && cnt <= kSortLane) {
+    uint32_t *h = hits + o0;
+    for (uint32_t j = 1; j < (uint32_t)cnt; ++j) {
+      const uint32_t x = h[j];
+      uint32_t i = j;
+      while (i > 0 && h[i - 1] > x) {
+        h[i] = h[i - 1];
+        --i;
+      }
+      h[i] = x;
+    }
+  }
+  uint64_t hm = __ballot(cnt > kSortLane);
+  while (hm) {
+    const int src = __ffsll((long long)hm) - 1;
+    hm &= hm - 1;
+    const uint64_t b0 = __shfl((unsigned long long)o0, src, kWave);
+    const uint64_t n = __shfl((unsigned long long)cnt, src, kWave);
+    uint32_t *h = hits + b0;
+    if (n <= LDSN) {
+      for (uint32_t i = lane; i < (uint32_t)n; i += kWave) lds[i] = h[i];
+      wave_sync_mem();
+      wave_bitonic_sort<uint32_t>(lds, (uint32_t)n, lane);
+      for (uint32_t i = lane; i < (uint32_t)n; i += kWave) h[i] = lds[i];
+    } else {
+      wave_bitonic_sort<uint64_t>(h, n, lane);  // very long hit lists: same network in global memory
+    }
+    wave_sync_mem();
+  }
+}
+
+__global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restrict__ offsets,
+                                                         uint32_t *__restrict__ hits, size_t nq, uint64_t cap) {
+  __shared__ uint32_t lds[kQWaves][kSortLds];
+  const size_t q = (size_t)blockIdx.x * kQThreads + threadIdx.x;
+  uint64_t o0, o1;
+  if (q < nq) {
+    o0 = offsets[q];
+    o1 = offsets[q + 1];
+  } else {
+    o0 = o1 = offsets[nq];  // lanes past the batch own an empty list at the very end: regions stay monotone
+  }
+  o0 = o0 < cap ? o0 : cap;  // a CSR that did not fit its buffer: nothing beyond the buffer is touched
+  o1 = o1 < cap ? o1 : cap;
+  wave_sort_lists<kSortLds, kRankBlock>(lds[threadIdx.x >> 6], o0, o1, hits, threadIdx.x & (kWave - 1));
+}
+
 // ---- single-pass kernel ----------------------------------------------------------------------------------
 // A workgroup owns kFTile = 1024 consecutive queries. It counts them (remembering each short window's hit
 // mask and the ids of its first hits), publishes its hit total, sums the totals of ALL earlier tiles, then
@@ -473,8 +614,9 @@ __device__ unsigned long long g_stamps[kFMaxTiles * 8];
 #define BIVX_STAMP(k)
 #endif
 
-// two workgroups per CU (8 waves per SIMD): keeps the kernel within 64 VGPRs
-template <bool LDS_DESC, bool F>
+// two workgroups per CU (8 waves per SIMD): keeps the kernel within 64 VGPRs.
+// S: every query's ids leave in ascending order (sorted on their way through the output stage; no second pass).
+template <bool LDS_DESC, bool F, bool S>
 __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThreads / 256)) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
                                                            const uint32_t *__restrict__ qhigh, size_t q_begin,
@@ -596,7 +738,41 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
     const uint64_t wpos0 = __shfl((unsigned long long)pos, 0, kWave);
     const uint32_t loff = (uint32_t)(pos - wpos0);
     const uint32_t wtotal = __shfl(loff + cnt[r], kWave - 1, kWave);
-    if (all_replay && wtotal >= kStageMin) {
+    if (S && all_replay) {
+      // Rounds of consecutive lanes whose lists fit half the stage together (a list has at most kLight ids): ids
+      // go to one half in slot order, every lane rank-sorts its own list into the other half, and that half is
+      // streamed out coalesced.
+      uint32_t *in = s_out[wave], *outb = s_out[wave] + kStage / 2;
+      uint32_t first = 0;
+      while (first < (uint32_t)kWave) {
+        const uint32_t base = __shfl(loff, (int)first, kWave);
+        const uint64_t fit = __ballot((uint32_t)lane >= first && loff + cnt[r] - base <= kStage / 2);
+        const uint64_t nofit = ~fit & (~0ull << first);
+        const uint32_t next = nofit ? (uint32_t)__ffsll((long long)nofit) - 1u : (uint32_t)kWave;
+        const bool mine = (uint32_t)lane >= first && (uint32_t)lane < next && cnt[r] != 0;
+        const uint32_t rel = loff - base;
+        if (mine) {
+          uint64_t mask = rp[r].mask;
+          uint32_t k = 0;
+          while (mask) {
+            const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
+            mask &= mask - 1;
+            in[rel + k] = hit_id(k, j);
+            ++k;
+          }
+        }
+        wave_sync_mem();
+        if (mine) rank_sort_list<kFusedRankBlock>(in, outb, rel, cnt[r]);
+        wave_sync_mem();
+        const uint32_t nthis = __shfl(loff + cnt[r], (int)next - 1, kWave) - base;
+        for (uint32_t i = lane; i < nthis; i += kWave) {
+          const uint64_t p = wpos0 + base + i;
+          if (p < cap) hits[p] = outb[i];
+        }
+        wave_sync_mem();
+        first = next;
+      }
+    } else if (all_replay && wtotal >= kStageMin) {
       uint32_t *buf = s_out[wave];
       for (uint32_t base = 0; base < wtotal; base += kStage) {
         if (cnt[r] != 0 && loff < base + kStage && loff + cnt[r] > base) {
@@ -633,6 +809,11 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
         qy[r].nseg = 0;
       }
       if (!all_replay) (void)enumerate_hits<Mode::Fill, F>(v, segs, qy[r], hits, pos, cap, nullptr);
+      if (S) {  // a wavefront with general-path queries: sort what it has just written (lists cut by `cap` stay cut)
+        wave_sync_mem();
+        const uint64_t e = pos + cnt[r];
+        wave_sort_lists<kStage, kFusedRankBlock>(s_out[wave], pos < cap ? pos : cap, e < cap ? e : cap, hits, lane);
+      }
     }
     pos += cnt[r];
   }
@@ -654,122 +835,6 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
 #ifdef BIVX_STAMPS
   if (threadIdx.x == 0) g_stamps[(blockIdx.x % kFMaxTiles) * 8 + 7] = tile;
 #endif
-}
-
-// ---- per-query ascending-id ordering of a CSR hit list ------------------------------------------------
-
-constexpr uint32_t kRankMax = 48;     // lists up to this long are rank-sorted by their lane (fast path)
-constexpr uint32_t kSortLane = 24;    // <= this many hits: the owning lane insertion-sorts in place
-constexpr uint32_t kSortLds = 4096;   // <= this many: the wavefront bitonic-sorts through LDS (16 KiB per wavefront)
-
-// Ascending sort of s[0..n) by one wavefront: the normalised bitonic network (every comparator puts the
-// minimum at the lower index), so virtual +inf pads at indices >= n never move and comparators that
-// touch them are simply skipped — any n sorts in place, in LDS or in global memory.
-template <typename IdxT>
-__device__ __forceinline__ void wave_bitonic_sort(uint32_t *s, IdxT n, int lane) {
-  IdxT np2 = 1;
-  while (np2 < n) np2 <<= 1;
-  for (IdxT k = 2; k <= np2; k <<= 1) {
-    for (IdxT t = lane; t < n; t += kWave) {
-      const IdxT p = t ^ (k - 1);
-      if (p > t && p < n) {
-        const uint32_t x = s[t], y = s[p];
-        if (x > y) {
-          s[t] = y;
-          s[p] = x;
-        }
-      }
-    }
-    wave_sync_mem();
-    for (IdxT j = k >> 2; j > 0; j >>= 1) {
-      for (IdxT t = lane; t < n; t += kWave) {
-        const IdxT p = t ^ j;
-        if (p > t && p < n) {
-          const uint32_t x = s[t], y = s[p];
-          if (x > y) {
-            s[t] = y;
-            s[p] = x;
-          }
-        }
-      }
-      wave_sync_mem();
-    }
-  }
-}
-
-__global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restrict__ offsets,
-                                                         uint32_t *__restrict__ hits, size_t nq) {
-  __shared__ uint32_t lds[kQWaves][kSortLds];
-  const size_t q = (size_t)blockIdx.x * kQThreads + threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  uint64_t o0, o1;
-  if (q < nq) {
-    o0 = offsets[q];
-    o1 = offsets[q + 1];
-  } else {
-    o0 = o1 = offsets[nq];  // lanes past the batch own an empty list at the very end: regions stay monotone
-  }
-  const uint64_t cnt = o1 - o0;
-
-  // Fast path, the usual case: every list of the wavefront is short and the 64 lists (adjacent in memory) fit the
-  // wavefront's LDS stage. The region is loaded with coalesced reads; every lane RANK-sorts its own list out of
-  // LDS (rank = how many elements are smaller; ids are distinct inside a query) — n^2 independent LDS reads and
-  // no dependent chain, unlike an insertion sort — into a second stage, which is streamed back coalesced.
-  {
-    const uint64_t wb = __shfl((unsigned long long)o0, 0, kWave);
-    const uint64_t we = __shfl((unsigned long long)o1, kWave - 1, kWave);
-    const bool lanes_ok = __all(cnt <= kRankMax) != 0;
-    if (lanes_ok && we - wb <= kSortLds / 2) {
-      const uint32_t wtotal = (uint32_t)(we - wb);
-      uint32_t *in = lds[wave], *outb = lds[wave] + kSortLds / 2;
-      if (__any(cnt > 1)) {
-        for (uint32_t i = lane; i < wtotal; i += kWave) in[i] = hits[wb + i];
-        wave_sync_mem();
-        const uint32_t off = (uint32_t)(o0 - wb), n = (uint32_t)cnt;
-        for (uint32_t i = 0; i < n; ++i) {
-          const uint32_t x = in[off + i];
-          uint32_t rank = 0;
-          for (uint32_t j = 0; j < n; ++j) rank += in[off + j] < x ? 1u : 0u;
-          outb[off + rank] = x;
-        }
-        wave_sync_mem();
-        for (uint32_t i = lane; i < wtotal; i += kWave) hits[wb + i] = outb[i];
-      }
-      return;
-    }
-  }
-
-  if (cnt > 1 && cnt <= kSortLane) {
-    uint32_t *h = hits + o0;
-    for (uint32_t j = 1; j < (uint32_t)cnt; ++j) {
-      const uint32_t x = h[j];
-      uint32_t i = j;
-      while (i > 0 && h[i - 1] > x) {
-        h[i] = h[i - 1];
-        --i;
-      }
-      h[i] = x;
-    }
-  }
-  uint64_t hm = __ballot(cnt > kSortLane);
-  while (hm) {
-    const int src = __ffsll((long long)hm) - 1;
-    hm &= hm - 1;
-    const uint64_t b0 = __shfl((unsigned long long)o0, src, kWave);
-    const uint64_t n = __shfl((unsigned long long)cnt, src, kWave);
-    uint32_t *h = hits + b0;
-    if (n <= kSortLds) {
-      uint32_t *s = lds[wave];
-      for (uint32_t i = lane; i < (uint32_t)n; i += kWave) s[i] = h[i];
-      wave_sync_mem();
-      wave_bitonic_sort<uint32_t>(s, (uint32_t)n, lane);
-      for (uint32_t i = lane; i < (uint32_t)n; i += kWave) h[i] = s[i];
-    } else {
-      wave_bitonic_sort<uint64_t>(h, n, lane);  // very long hit lists: same network in global memory
-    }
-    wave_sync_mem();
-  }
 }
 
 inline bool fits_lds(const IndexView &v) { return v.nseg <= kLdsSegs && v.nchrom <= kLdsChroms; }
@@ -819,7 +884,7 @@ size_t fused_workspace_timeouts_offset() { return (size_t)kWsTimeouts * sizeof(u
 
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
-                       void *d_ws, bool self_clean, hipStream_t s) {
+                       void *d_ws, bool self_clean, bool sort_ids, hipStream_t s) {
   if (q == 0) {
     BIVX_HIP(hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), s));
     return 0;
@@ -834,18 +899,28 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     const dim3 grid(tiles), block(kFThreads);
     const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
     const int sc = self_clean ? 1 : 0;
-    if (lds && !flt)
-      hipLaunchKernelGGL((k_query_fused<true, false>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets,
-                         d_hits, cap, ws, sc);
-    else if (lds)
-      hipLaunchKernelGGL((k_query_fused<true, true>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets,
-                         d_hits, cap, ws, sc);
-    else if (!flt)
-      hipLaunchKernelGGL((k_query_fused<false, false>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets,
-                         d_hits, cap, ws, sc);
-    else
-      hipLaunchKernelGGL((k_query_fused<false, true>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets,
-                         d_hits, cap, ws, sc);
+    // Ordering ids inside the kernel pays while a wavefront's 64 lists fit half its output stage (one round, all
+    // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
+    // ordered by k_sort_hits afterwards, whose stage is eight times larger.
+    const bool sort_inside = sort_ids && cap <= (uint64_t)kFusedSortMaxAvg * q;
+#define BIVX_LAUNCH_FUSED(L, FL, SO)                                                                              \
+  hipLaunchKernelGGL((k_query_fused<L, FL, SO>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, \
+                     d_hits, cap, ws, sc)
+    switch ((lds ? 4 : 0) | (flt ? 2 : 0) | (sort_inside ? 1 : 0)) {
+      case 0: BIVX_LAUNCH_FUSED(false, false, false); break;
+      case 1: BIVX_LAUNCH_FUSED(false, false, true); break;
+      case 2: BIVX_LAUNCH_FUSED(false, true, false); break;
+      case 3: BIVX_LAUNCH_FUSED(false, true, true); break;
+      case 4: BIVX_LAUNCH_FUSED(true, false, false); break;
+      case 5: BIVX_LAUNCH_FUSED(true, false, true); break;
+      case 6: BIVX_LAUNCH_FUSED(true, true, false); break;
+      default: BIVX_LAUNCH_FUSED(true, true, true); break;
+    }
+#undef BIVX_LAUNCH_FUSED
+    if (sort_ids && !sort_inside) {
+      BIVX_HIP(hipGetLastError());
+      if (int rc = launch_sort_hits(d_offsets + q0, d_hits, q1 - q0, cap, s)) return rc;
+    }
   }
   BIVX_HIP(hipGetLastError());
   return 0;
@@ -858,9 +933,9 @@ extern "C" int bivx_debug_stamps(unsigned long long *out, size_t n) {
 }
 #endif
 
-int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, hipStream_t s) {
+int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, uint64_t cap, hipStream_t s) {
   if (q == 0) return 0;
-  hipLaunchKernelGGL(k_sort_hits, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q);
+  hipLaunchKernelGGL(k_sort_hits, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q, cap);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

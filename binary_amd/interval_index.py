@@ -203,7 +203,8 @@ class IntervalIndex:
 
     def query_device(self, qlow, qhigh, offsets, hits, workspace=None, qchrom=None, sort_by_id: bool = False,
                      flt=None):
-        """Single-pass count+prefix+fill into caller-owned buffers (bivx_query_dev[_f]); asynchronous.
+        """Single-pass count+prefix+fill into caller-owned buffers (bivx_query_dev_s); asynchronous.
+        sort_by_id: ids ascend inside every query (ordered by the same kernel), else index order.
         offsets[-1] is the true hit total even if it exceeds hits.numel() (then only a prefix was written).
         flt: optional device_filter(...)."""
         self._ensure_built()
@@ -217,12 +218,10 @@ class IntervalIndex:
         if workspace is not None:
             _check_dev_tensor(workspace, "workspace", None, 1)
         s = C.c_void_p(torch.cuda.current_stream(qlow.device).cuda_stream)
-        capi.check(self._L.bivx_query_dev_f(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q,
-                                            None if flt is None else C.byref(flt), _tptr(offsets), _tptr(hits),
-                                            hits.numel(), _tptr(workspace),
+        capi.check(self._L.bivx_query_dev_s(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q,
+                                            None if flt is None else C.byref(flt), 1 if sort_by_id else 0,
+                                            _tptr(offsets), _tptr(hits), hits.numel(), _tptr(workspace),
                                             0 if workspace is None else workspace.numel(), s))
-        if sort_by_id:
-            capi.check(self._L.bivx_sort_hits_dev(self._h, _tptr(offsets), _tptr(hits), q, s))
         return offsets, hits
 
     def find_overlaps_device(self, qlow, qhigh, qchrom=None, sort_by_id: bool = False):

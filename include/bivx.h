@@ -48,7 +48,7 @@ typedef enum bivx_status {
 #define BIVX_NO_HIT 0xFFFFFFFFu
 
 /* ABI version of this header: major << 16 | minor. */
-#define BIVX_ABI_VERSION 0x00010001u
+#define BIVX_ABI_VERSION 0x00010002u
 uint32_t bivx_abi_version(void);
 const char *bivx_last_error(void);
 
@@ -182,6 +182,13 @@ int bivx_query_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint
                      const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, uint64_t *d_offsets,
                      uint32_t *d_hit_ids, uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes,
                      void *stream);
+/* bivx_query_dev_f whose ids leave in ascending order inside every query when sort_by_id != 0 — the order
+ * bivx_sort_hits_dev gives, produced by the same kernel on the ids' way out instead of by a second pass over
+ * the CSR (the facade's find_overlaps order, interval_tree.hpp:306-334 as a set). */
+int bivx_query_dev_s(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                     const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, int sort_by_id,
+                     uint64_t *d_offsets, uint32_t *d_hit_ids, uint64_t hit_capacity, void *d_workspace,
+                     size_t workspace_bytes, void *stream);
 
 /* ---- introspection (bench / DESIGN.md numbers) -------------------------------------------------- */
 typedef struct bivx_stats {

@@ -339,6 +339,42 @@ def test_single_pass_equals_two_pass_and_oracle(IntervalIndex, oracle):
         assert np.array_equal(got.astype(np.int64), sel[oracle.sorted_csr(off_o, hits_o)])
 
 
+@pytest.mark.parametrize("span,max_len", [(60_000_000, 1000), (600_000, 3000)])  # ~2 and ~40 ids per query
+def test_single_pass_sorted_ids_any_capacity(IntervalIndex, span, max_len):
+    """sort_by_id in the single pass: ids ascend inside every query whichever way they are ordered (inside the
+    kernel when the buffer says few ids per query, by the follow-up pass otherwise), a buffer smaller than the
+    result keeps exact offsets, and nothing past the buffer's capacity is ever written."""
+    import torch
+    from binary_amd import synth
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    low, high = synth.gen_intervals(200_000, span, max_len)
+    low[:40] = 0                                   # a few chromosome-long intervals: wavefront-path queries too
+    high[:40] = span
+    qlo, qhi = synth.gen_range_queries(150_001, span, max_len)
+    qhi[:20] = qlo[:20] + span // 50
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        ref_off, ref_hits = idx.find_overlaps(qlo, qhi, sort_by_id=True)   # two-pass + k_sort_hits
+        H = int(ref_off[-1])
+        guard = 4096
+        for cap in (H, 5 * qlo.size + 7, H + 5 * qlo.size, H // 2, 1000):
+            off = torch.empty(qlo.size + 1, dtype=torch.int64, device=dev)
+            buf = torch.full((cap + guard,), -2, dtype=torch.int32, device=dev)
+            idx.query_device(to(qlo), to(qhi), off, buf[:cap], sort_by_id=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), ref_off), cap
+            assert bool((buf[cap:] == -2).all()), cap                  # the guard words are untouched
+            got = buf[:cap].cpu().numpy().view(np.uint32)
+            if cap >= H:
+                assert np.array_equal(got[:H], ref_hits), cap
+            else:  # every list that fits entirely is exact and ascending; the one the capacity cuts is unspecified
+                last = int(np.searchsorted(ref_off, cap, side="right")) - 1  # queries [0, last) fit entirely
+                n = int(ref_off[last])
+                assert np.array_equal(got[:n], ref_hits[:n]), cap
+
+
 def test_single_pass_index_owned_workspace(IntervalIndex):
     """workspace=None: the index keeps a self-cleaning prefix workspace per stream; results must not change over
     repeated calls, different batch sizes, two streams, or a rebuild in between."""
