@@ -590,6 +590,10 @@ constexpr int kFR = 1;  // queries per thread. (More per thread was measured and
 constexpr int kFTile = kFThreads * kFR;
 constexpr unsigned kFMaxTiles = 1024;
 constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per round before streaming them out
+#ifndef BIVX_GATHER
+#define BIVX_GATHER 8
+#endif
+constexpr uint32_t kGather = BIVX_GATHER;  // ids a lane fetches per step when it replays a window in phase 2
 constexpr uint32_t kStageMin = 320;  // ... when it has at least this many (5 per lane); below that lanes store directly
 constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
@@ -734,6 +738,25 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
       if (rp[r].kept && k < kKeep) return kept[k];
       return rp[r].packed ? v.rec[rp[r].al + j].y : v.id[rp[r].al + j];
     };
+    // ids of the replayed hits k0 .. k1-1 (`mrem`: the mask bits not consumed yet), handed to put(k, id). kGather
+    // ids are fetched per step with all their loads in flight together: one load per hit in a while-loop made
+    // every lane wait a full memory latency per id, which was most of phase 2 when queries have ~16 hits.
+    auto replay = [&](uint64_t &mrem, uint32_t k0, uint32_t k1, auto put) {
+      for (uint32_t k = k0; k < k1; k += kGather) {
+        uint32_t js[kGather], ids[kGather];
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; ++i) {
+          js[i] = mrem ? (uint32_t)__ffsll((long long)mrem) - 1u : 0u;
+          if (k + i < k1) mrem &= mrem - 1;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; ++i)
+          if (k + i < k1) ids[i] = hit_id(k + i, js[i]);
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; ++i)
+          if (k + i < k1) put(k + i, ids[i]);
+      }
+    };
     const bool all_replay = __all(rp[r].ok);
     const uint64_t wpos0 = __shfl((unsigned long long)pos, 0, kWave);
     const uint32_t loff = (uint32_t)(pos - wpos0);
@@ -752,14 +775,8 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
         const bool mine = (uint32_t)lane >= first && (uint32_t)lane < next && cnt[r] != 0;
         const uint32_t rel = loff - base;
         if (mine) {
-          uint64_t mask = rp[r].mask;
-          uint32_t k = 0;
-          while (mask) {
-            const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
-            mask &= mask - 1;
-            in[rel + k] = hit_id(k, j);
-            ++k;
-          }
+          uint64_t mrem = rp[r].mask;
+          replay(mrem, 0u, cnt[r], [&](uint32_t k, uint32_t id) { in[rel + k] = id; });
         }
         wave_sync_mem();
         if (mine) rank_sort_list<kFusedRankBlock>(in, outb, rel, cnt[r]);
@@ -774,17 +791,14 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
       }
     } else if (all_replay && wtotal >= kStageMin) {
       uint32_t *buf = s_out[wave];
+      uint64_t mrem = rp[r].mask;
+      uint32_t kdone = 0;  // a lane's hits enter the stage in order, over one or more consecutive rounds
       for (uint32_t base = 0; base < wtotal; base += kStage) {
-        if (cnt[r] != 0 && loff < base + kStage && loff + cnt[r] > base) {
-          uint64_t mask = rp[r].mask;
-          uint32_t k = 0;
-          while (mask) {
-            const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
-            mask &= mask - 1;
-            const uint32_t o = loff + k;
-            if (o >= base && o < base + kStage) buf[o - base] = hit_id(k, j);
-            ++k;
-          }
+        if (kdone < cnt[r] && loff < base + kStage) {
+          const uint32_t room = base + kStage - loff;
+          const uint32_t kend = cnt[r] < room ? cnt[r] : room;
+          replay(mrem, kdone, kend, [&](uint32_t k, uint32_t id) { buf[loff + k - base] = id; });
+          kdone = kend;
         }
         wave_sync_mem();
         const uint32_t nthis = wtotal - base < kStage ? wtotal - base : kStage;
@@ -797,15 +811,10 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
     } else {
       // few ids per lane (or a wavefront that holds general-path queries): every lane stores its own list
       if (rp[r].ok) {
-        uint64_t mask = rp[r].mask;
-        uint32_t k = 0;
-        while (mask) {
-          const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
-          mask &= mask - 1;
-          const uint32_t hid = hit_id(k, j);
-          if (pos + k < cap) hits[pos + k] = hid;
-          ++k;
-        }
+        uint64_t mrem = rp[r].mask;
+        replay(mrem, 0u, cnt[r], [&](uint32_t k, uint32_t id) {
+          if (pos + k < cap) hits[pos + k] = id;
+        });
         qy[r].nseg = 0;
       }
       if (!all_replay) (void)enumerate_hits<Mode::Fill, F>(v, segs, qy[r], hits, pos, cap, nullptr);

@@ -12,7 +12,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SORTED = "--sorted" in sys.argv
-extra = " ".join(a for a in sys.argv[1:] if a != "--sorted")
+DENSE = "--dense" in sys.argv  # config-5 density: self-overlap, ~17 ids per query
+extra = " ".join(a for a in sys.argv[1:] if a not in ("--sorted", "--dense"))
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "clean"])
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "-j8", f"EXTRA=-DBIVX_STAMPS {extra}"])
 from binary_amd import IntervalIndex, synth, capi  # noqa: E402
@@ -21,16 +22,19 @@ dev = torch.device("cuda:0")
 L = int(synth.HG38_LENGTHS[0])
 lo, hi = synth.gen_intervals(1_000_000, L, 1000, 0)
 ql, qh = synth.gen_point_queries(1_000_000, L, 0)
+if DENSE:
+    lo, hi = synth.gen_intervals(1_000_000, 62_000_000, 1000, 0)
+    ql, qh = lo.copy(), hi.copy()
 if SORTED:
-    ql = np.sort(ql)
-    qh = ql.copy()
+    o = np.argsort(ql, kind="stable")
+    ql, qh = ql[o], qh[o]
 to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
 idx = IntervalIndex(0)
 idx.insert_node(lo, hi)
 idx.build()
 Q = ql.size
 off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
-hits = torch.empty(3_000_000, dtype=torch.int32, device=dev)
+hits = torch.empty(30_000_000 if DENSE else 3_000_000, dtype=torch.int32, device=dev)
 ws = torch.empty(idx.query_workspace_bytes(Q), dtype=torch.uint8, device=dev)
 dql, dqh = to(ql), to(qh)
 for _ in range(20):
