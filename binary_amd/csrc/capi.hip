@@ -44,7 +44,7 @@ struct bivx_index {
   uint32_t *d_table = nullptr;
   SegDesc *d_seg = nullptr;
   uint32_t *d_chrom_seg = nullptr;
-  uint32_t nchrom = 0, nseg = 0;
+  uint32_t nchrom = 0, nseg = 0, max_segs = 0;
   uint64_t nentries = 0;
   size_t built_n = 0;
   double build_ms = 0.0;
@@ -115,7 +115,7 @@ void free_built(bivx_index *idx) {
   idx->d_table = nullptr;
   idx->d_seg = nullptr;
   idx->d_chrom_seg = nullptr;
-  idx->nchrom = idx->nseg = 0;
+  idx->nchrom = idx->nseg = idx->max_segs = 0;
   idx->nentries = 0;
   idx->built = false;
 }
@@ -286,6 +286,7 @@ IndexView view_of(const bivx_index *idx) {
   v.chrom_seg = idx->d_chrom_seg;
   v.nchrom = idx->nchrom;
   v.nseg = idx->nseg;
+  v.max_segs = idx->max_segs;
   v.flt_kind = BIVX_FILTER_NONE;
   v.flt_dist = 0;
   v.flt_strand = 0;
@@ -504,6 +505,9 @@ int bivx_build(bivx_index *idx) {
   BIVX_HIP(hipStreamSynchronize(s));
   idx->nchrom = nchrom;
   idx->nseg = nseg;
+  idx->max_segs = 0;
+  for (uint32_t c = 0; c < nchrom; ++c)
+    idx->max_segs = std::max(idx->max_segs, plan.chrom_seg[c + 1] - plan.chrom_seg[c]);
   idx->nentries = plan.nentries;
   idx->built = true;
   idx->built_n = n;

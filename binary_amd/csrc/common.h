@@ -55,6 +55,7 @@ struct IndexView {
   const uint32_t *chrom_seg;  // nchrom + 1: segments of chromosome c are [chrom_seg[c], chrom_seg[c+1])
   uint32_t nchrom;
   uint32_t nseg;
+  uint32_t max_segs;          // most segments any one chromosome has
   // optional post-filter fused into the enumeration (bivx_filter): a candidate must pass it as well
   uint32_t flt_kind;          // BIVX_FILTER_*
   uint32_t flt_dist;

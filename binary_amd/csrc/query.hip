@@ -252,30 +252,36 @@ struct Query {
 // What a lane remembers from a counting pass so that the fill needs no second look at the intervals:
 // valid when the query touched one segment and its window fitted the lane budget.
 struct Replay {
-  uint32_t al;    // aligned first slot of the window
+  uint32_t al;    // aligned first slot of the (first recorded) window
   uint64_t mask;  // bit j set: slot al + j is a hit
   bool ok;
   bool kept;      // ids of the first min(hits, kKeep) hits were written to the caller's `keep` slots
   bool packed;    // the window was read from packed records: ids sit in rec[].y
+  uint32_t nrec;  // windows recorded (those with hits): the first one above, later ones in the lane's LDS slots
 };
+// A query over several segments (several length classes on its chromosome) records up to kMaxRec windows: the
+// second goes to the lane's `keep` slot (free: ids are only kept for one-segment queries), the third to its
+// `xrec` slot, each as three words (al | packed, mask low, mask high); al is even, so bit 0 is free.
+constexpr uint32_t kMaxRec = 3;
 
 // The whole hit enumeration of one query per lane, wavefront-converged (all 64 lanes must call it).
 //   Count: returns the number of hits (and fills *rp).   Any: returns the smallest hit id (BIVX_NO_HIT if none).
 //   Fill:  writes hit ids to hits_base[dst_pos ..), in index order, only positions below `cap`;
 //          returns the number of hits.
-template <Mode M, bool F>
+template <Mode M, bool F, bool MS = false>
 __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const SegDesc *segs, const Query &qy,
                                                    uint32_t *hits_base, uint64_t dst_pos, uint64_t cap,
-                                                   Replay *rp, uint32_t *keep = nullptr) {
+                                                   Replay *rp, uint32_t *keep = nullptr, uint32_t *xrec = nullptr) {
   const int lane = threadIdx.x & (kWave - 1);
   uint32_t acc = (M == Mode::Any) ? BIVX_NO_HIT : 0u;
   const uint32_t lo = qy.lo, hi = qy.hi;
   if (M == Mode::Count && rp) {
     rp->al = 0;
     rp->mask = 0;
-    rp->ok = qy.nseg <= 1;
+    rp->ok = MS || qy.nseg <= 1;
     rp->kept = false;
     rp->packed = false;
+    rp->nrec = 0;
   }
   // the segment loop is wavefront-uniform so the cooperative part may use __ballot / __shfl
   for (uint32_t k = 0; __any(k < qy.nseg); ++k) {
@@ -293,21 +299,29 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
     if (nonempty && !heavy) {
       uint32_t al;
       uint64_t mask;
+      const bool want = M == Mode::Count && packed && keep != nullptr && qy.nseg == 1;
       if (packed) {
-        const bool want = M == Mode::Count && keep != nullptr && qy.nseg == 1;
         mask = light_mask_packed<F>(v, w, lo, hi, qy.aux, al, want ? keep : nullptr);
-        if (M == Mode::Count && rp) {
-          rp->kept = want;
-          rp->packed = true;
-        }
       } else {
         mask = light_mask_pairs<F>(v, w.a, w.b, lo, hi, qy.aux, al);
       }
       if (M == Mode::Count) {
         acc += (uint32_t)__popcll(mask);
-        if (rp) {
-          rp->al = al;
-          rp->mask = mask;
+        if (rp && (!MS || mask)) {  // several segments: only windows with hits are worth a record
+          if (!MS || rp->nrec == 0) {
+            rp->al = al;
+            rp->mask = mask;
+            rp->kept = want;
+            rp->packed = packed;
+          } else if (rp->nrec < kMaxRec) {
+            uint32_t *slot = rp->nrec == 1 ? keep : xrec;
+            slot[0] = al | (packed ? 1u : 0u);
+            slot[1] = (uint32_t)mask;
+            slot[2] = (uint32_t)(mask >> 32);
+          } else {
+            rp->ok = false;
+          }
+          ++rp->nrec;
         }
       } else {
         while (mask) {
@@ -620,7 +634,8 @@ __device__ unsigned long long g_stamps[kFMaxTiles * 8];
 
 // two workgroups per CU (8 waves per SIMD): keeps the kernel within 64 VGPRs.
 // S: every query's ids leave in ascending order (sorted on their way through the output stage; no second pass).
-template <bool LDS_DESC, bool F, bool S>
+// MS: the index has chromosomes with several segments; queries record up to kMaxRec windows for the replay.
+template <bool LDS_DESC, bool F, bool S, bool MS>
 __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThreads / 256)) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
                                                            const uint32_t *__restrict__ qhigh, size_t q_begin,
@@ -635,6 +650,7 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   __shared__ uint64_t s_base;
   __shared__ uint4 s_keep[kFR][kFThreads];  // ids of each query's first kKeep hits (thread-private slots)
   __shared__ uint32_t s_out[kFWaves][kStage];  // per-wavefront staging of the output ids
+  __shared__ uint4 s_xrec[MS ? kFThreads : 1];  // a query's third recorded window (thread-private slots)
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
@@ -663,8 +679,9 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   for (int r = 0; r < kFR; ++r) qy[r] = load_query<F>(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
 #pragma unroll
   for (int r = 0; r < kFR; ++r) {
-    cnt[r] = enumerate_hits<Mode::Count, F>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
-                                         reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x]));
+    cnt[r] = enumerate_hits<Mode::Count, F, MS>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
+                                             reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x]),
+                                             reinterpret_cast<uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]));
     tsum += cnt[r];
   }
 
@@ -734,24 +751,47 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
       if (q == q_end - 1) offsets[q_end] = pos + cnt[r];
     }
     const uint32_t *kept = reinterpret_cast<const uint32_t *>(&s_keep[r][threadIdx.x]);
-    auto hit_id = [&](uint32_t k, uint32_t j) -> uint32_t {  // id of the k-th hit, which sits in slot al + j
-      if (rp[r].kept && k < kKeep) return kept[k];
-      return rp[r].packed ? v.rec[rp[r].al + j].y : v.id[rp[r].al + j];
-    };
-    // ids of the replayed hits k0 .. k1-1 (`mrem`: the mask bits not consumed yet), handed to put(k, id). kGather
-    // ids are fetched per step with all their loads in flight together: one load per hit in a while-loop made
-    // every lane wait a full memory latency per id, which was most of phase 2 when queries have ~16 hits.
-    auto replay = [&](uint64_t &mrem, uint32_t k0, uint32_t k1, auto put) {
+    // The replay cursor walks the lane's recorded windows in segment order: `mrem` holds the bits of the current
+    // window that are not consumed yet. replay(k0, k1, put) hands the ids of hits k0 .. k1-1 (consecutive calls
+    // continue where the last one stopped) to put(k, id). kGather ids are fetched per step with all their loads in
+    // flight together: one load per hit in a while-loop made every lane wait a full memory latency per id, which
+    // was most of phase 2 when queries have ~16 hits.
+    uint64_t mrem = rp[r].mask;
+    uint32_t cur_al = rp[r].al, cur_rec = 1;
+    bool cur_packed = rp[r].packed;
+    const uint32_t *xrec = reinterpret_cast<const uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]);
+    auto replay = [&](uint32_t k0, uint32_t k1, auto put) {
       for (uint32_t k = k0; k < k1; k += kGather) {
-        uint32_t js[kGather], ids[kGather];
+        uint32_t slot[kGather], ids[kGather], pk = 0;
 #pragma unroll
         for (uint32_t i = 0; i < kGather; ++i) {
-          js[i] = mrem ? (uint32_t)__ffsll((long long)mrem) - 1u : 0u;
-          if (k + i < k1) mrem &= mrem - 1;
+          slot[i] = 0;
+          if (k + i < k1) {
+            if (MS) {
+              while (mrem == 0 && cur_rec < kMaxRec) {  // next recorded window (there is one: k < the hit count)
+                const uint32_t *w = cur_rec == 1 ? kept : xrec;
+                cur_al = w[0] & ~1u;
+                cur_packed = (w[0] & 1u) != 0;
+                mrem = (uint64_t)w[1] | (uint64_t)w[2] << 32;
+                ++cur_rec;
+              }
+            }
+            slot[i] = (uint32_t)__ffsll((long long)mrem) - 1u;
+            if (MS) {
+              slot[i] += cur_al;
+              pk |= (cur_packed ? 1u : 0u) << i;
+            }
+            mrem &= mrem - 1;
+          }
         }
 #pragma unroll
-        for (uint32_t i = 0; i < kGather; ++i)
-          if (k + i < k1) ids[i] = hit_id(k + i, js[i]);
+        for (uint32_t i = 0; i < kGather; ++i) {
+          if (k + i < k1) {
+            if (rp[r].kept && k + i < kKeep) ids[i] = kept[k + i];
+            else if (MS) ids[i] = (pk >> i & 1u) ? v.rec[slot[i]].y : v.id[slot[i]];
+            else ids[i] = rp[r].packed ? v.rec[rp[r].al + slot[i]].y : v.id[rp[r].al + slot[i]];
+          }
+        }
 #pragma unroll
         for (uint32_t i = 0; i < kGather; ++i)
           if (k + i < k1) put(k + i, ids[i]);
@@ -774,10 +814,7 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
         const uint32_t next = nofit ? (uint32_t)__ffsll((long long)nofit) - 1u : (uint32_t)kWave;
         const bool mine = (uint32_t)lane >= first && (uint32_t)lane < next && cnt[r] != 0;
         const uint32_t rel = loff - base;
-        if (mine) {
-          uint64_t mrem = rp[r].mask;
-          replay(mrem, 0u, cnt[r], [&](uint32_t k, uint32_t id) { in[rel + k] = id; });
-        }
+        if (mine) replay(0u, cnt[r], [&](uint32_t k, uint32_t id) { in[rel + k] = id; });
         wave_sync_mem();
         if (mine) rank_sort_list<kFusedRankBlock>(in, outb, rel, cnt[r]);
         wave_sync_mem();
@@ -791,13 +828,12 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
       }
     } else if (all_replay && wtotal >= kStageMin) {
       uint32_t *buf = s_out[wave];
-      uint64_t mrem = rp[r].mask;
       uint32_t kdone = 0;  // a lane's hits enter the stage in order, over one or more consecutive rounds
       for (uint32_t base = 0; base < wtotal; base += kStage) {
         if (kdone < cnt[r] && loff < base + kStage) {
           const uint32_t room = base + kStage - loff;
           const uint32_t kend = cnt[r] < room ? cnt[r] : room;
-          replay(mrem, kdone, kend, [&](uint32_t k, uint32_t id) { buf[loff + k - base] = id; });
+          replay(kdone, kend, [&](uint32_t k, uint32_t id) { buf[loff + k - base] = id; });
           kdone = kend;
         }
         wave_sync_mem();
@@ -811,8 +847,7 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
     } else {
       // few ids per lane (or a wavefront that holds general-path queries): every lane stores its own list
       if (rp[r].ok) {
-        uint64_t mrem = rp[r].mask;
-        replay(mrem, 0u, cnt[r], [&](uint32_t k, uint32_t id) {
+        replay(0u, cnt[r], [&](uint32_t k, uint32_t id) {
           if (pos + k < cap) hits[pos + k] = id;
         });
         qy[r].nseg = 0;
@@ -912,9 +947,13 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
     // ordered by k_sort_hits afterwards, whose stage is eight times larger.
     const bool sort_inside = sort_ids && cap <= (uint64_t)kFusedSortMaxAvg * q;
-#define BIVX_LAUNCH_FUSED(L, FL, SO)                                                                              \
-  hipLaunchKernelGGL((k_query_fused<L, FL, SO>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, \
-                     d_hits, cap, ws, sc)
+#define BIVX_LAUNCH_FUSED(L, FL, SO)                                                                           \
+  if (v.max_segs > 1)                                                                                              \
+    hipLaunchKernelGGL((k_query_fused<L, FL, SO, true>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, \
+                       d_offsets, d_hits, cap, ws, sc);                                                            \
+  else                                                                                                             \
+    hipLaunchKernelGGL((k_query_fused<L, FL, SO, false>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, \
+                       d_offsets, d_hits, cap, ws, sc)
     switch ((lds ? 4 : 0) | (flt ? 2 : 0) | (sort_inside ? 1 : 0)) {
       case 0: BIVX_LAUNCH_FUSED(false, false, false); break;
       case 1: BIVX_LAUNCH_FUSED(false, false, true); break;

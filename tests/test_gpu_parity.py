@@ -484,3 +484,40 @@ def test_clustered_intervals_long_cells_are_trimmed(IntervalIndex, oracle):
     assert cnt.max() > 50_000
     exp_first = np.where(cnt > 0, hits_o[np.minimum(off_o[:-1].astype(np.int64), hits_o.size - 1)], M32)
     assert np.array_equal(first.astype(np.int64), exp_first)
+
+
+@pytest.mark.parametrize("max_len", [10_000, 100_000, 1_000_000])
+def test_single_pass_over_several_length_classes(IntervalIndex, oracle, max_len):
+    """Log-uniform lengths (an SV-like spectrum) make the planner cut 2 .. 7 length classes on one chromosome, so a
+    query meets several segments: the single pass records up to three windows per query for its output phase
+    and enumerates again beyond that; all of it must give the two-pass CSR and the reference's sets."""
+    import torch
+    rng = np.random.default_rng(max_len)
+    span, n, q = 25_000_000, 100_000, 60_001
+    low = rng.integers(0, span - max_len - 1, size=n).astype(np.uint32)
+    high = low + np.exp(rng.uniform(np.log(50), np.log(max_len), size=n)).astype(np.uint32)
+    qlo = rng.integers(0, span, size=q).astype(np.uint32)
+    qhi = qlo + rng.integers(0, 200, size=q).astype(np.uint32)
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        assert idx.stats()["n_segments"] >= 2
+        ref_off, ref_hits = idx.find_overlaps(qlo, qhi, sort_by_id=False)          # two-pass, index order
+        H = int(ref_off[-1])
+        for sort in (False, True):
+            off = torch.empty(q + 1, dtype=torch.int64, device=dev)
+            hits = torch.full((H,), -1, dtype=torch.int32, device=dev)
+            idx.query_device(to(qlo), to(qhi), off, hits, sort_by_id=sort)
+            torch.cuda.synchronize()
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), ref_off)
+            got = hits.cpu().numpy().view(np.uint32)
+            if not sort:
+                assert np.array_equal(got, ref_hits)
+        assert idx.stats()["prefix_timeouts"] == 0
+    # `got` is the id-sorted CSR now: the reference's sets
+    t = oracle.OracleTree(low, high)
+    off_o, hits_o = t.find_overlaps_batch(qlo, qhi)
+    assert np.array_equal(ref_off, off_o.astype(np.uint64))
+    assert np.array_equal(got.astype(np.int64), oracle.sorted_csr(off_o, hits_o))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""SV-like length spectrum: 1 M intervals with log-uniform lengths 50 bp .. 10 Mbp on one chromosome, 1 M point queries.
-Prints the length classes the planner chose and the single-pass time."""
+"""SV-like length spectrum: 1 M intervals with log-uniform lengths 50 bp .. MAXLEN (argv[1], default 10 Mbp) on one
+chromosome, 1 M point queries. Prints the length classes the planner chose and the single-pass time."""
 import sys
 import numpy as np
 import torch
@@ -10,7 +10,8 @@ rng = np.random.default_rng(5)
 L = 248_956_422
 n = q = 1_000_000
 low = rng.integers(0, L - 10_000_001, size=n).astype(np.uint32)
-ln = np.exp(rng.uniform(np.log(50), np.log(10_000_000), size=n)).astype(np.uint32)
+MAXLEN = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+ln = np.exp(rng.uniform(np.log(50), np.log(MAXLEN), size=n)).astype(np.uint32)
 high = low + ln
 qlo = rng.integers(0, L, size=q).astype(np.uint32)
 dev = torch.device("cuda:0")
@@ -32,4 +33,6 @@ def timed(fn, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 t = timed(lambda: idx.query_device(dq, dq, off, hits))
+t2 = timed(lambda: idx.count_overlaps_device(dq, dq, offsets=off, workspace=ws))
+print(f"maxlen={MAXLEN} count-only {t2:.3f} ms;", end=" ")
 print(f"segments={st['n_segments']} build_ms={st['build_ms']:.2f} H={H} ({H/q:.1f} hits/query) single-pass {t:.3f} ms = {q/t/1e6:.2f} G q/s, {H/t/1e6:.2f} G hits/s")
