@@ -29,6 +29,8 @@ constexpr uint32_t kLight = 64;      // window slots a lane reads by itself; lon
 #define BIVX_TRIM 512
 #endif
 constexpr uint32_t kTrim = BIVX_TRIM;  // wavefront windows longer than this are first trimmed by a 64-ary search
+constexpr uint32_t kRowsWide = 4;    // rows of 64 slots the wavefront-cooperative path keeps in flight ...
+constexpr uint32_t kRowsLean = 1;    // ... and in the one-segment single-pass kernel, which must stay spill-free in 64 VGPRs
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
 constexpr uint32_t kLdsChroms = 511; // ... with chrom_seg (2 KiB); larger indexes read them from global
 
@@ -268,7 +270,7 @@ constexpr uint32_t kMaxRec = 3;
 //   Count: returns the number of hits (and fills *rp).   Any: returns the smallest hit id (BIVX_NO_HIT if none).
 //   Fill:  writes hit ids to hits_base[dst_pos ..), in index order, only positions below `cap`;
 //          returns the number of hits.
-template <Mode M, bool F, bool MS = false>
+template <Mode M, bool F, bool MS = false, uint32_t kHeavyRows = kRowsWide>
 __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const SegDesc *segs, const Query &qy,
                                                    uint32_t *hits_base, uint64_t dst_pos, uint64_t cap,
                                                    Replay *rp, uint32_t *keep = nullptr, uint32_t *xrec = nullptr) {
@@ -355,7 +357,17 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       };
       if (M == Mode::Count) {
         uint32_t c = 0;
-        for (uint32_t j = ca + lane; j < cb; j += kWave) c += is_hit(j) ? 1u : 0u;
+        for (uint32_t j0 = ca + lane; j0 < cb; j0 += kHeavyRows * kWave) {  // kHeavyRows rows of 64 slots in flight
+          uint2 e[kHeavyRows];
+#pragma unroll
+          for (uint32_t r = 0; r < kHeavyRows; ++r)
+            if (j0 + r * kWave < cb) e[r] = v.se[j0 + r * kWave];
+#pragma unroll
+          for (uint32_t r = 0; r < kHeavyRows; ++r) {
+            const uint32_t j = j0 + r * kWave;
+            if (j < cb && e[r].x <= ch && e[r].y >= cl && (!F || filter_accept(v, cl, ch, cx, e[r].x, e[r].y, v.id[j]))) ++c;
+          }
+        }
         c = wave_sum(c);
         if (lane == src) acc += c;
       } else if (M == Mode::Any) {
@@ -366,17 +378,33 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
         if (lane == src) acc = min(acc, m);
       } else {
         // ballot compaction keeps ascending slot order: the output does not depend on which path ran
+        // kHeavyRows rows of 64 slots are loaded together, ids included (a row's ids are one coalesced load; fetching
+        // them only for hits would put a dependent load between the ballot and the store of every row).
         const uint64_t pos0 = __shfl((unsigned long long)(dst_pos + acc), src, kWave);
         uint32_t written = 0;
-        for (uint32_t j0 = ca; j0 < cb; j0 += kWave) {
-          const uint32_t j = j0 + lane;
-          const bool hit = j < cb && is_hit(j);
-          const uint64_t m = __ballot(hit);
-          if (hit) {
-            const uint64_t p = pos0 + written + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (p < cap) hits_base[p] = v.id[j];
+        for (uint32_t j0 = ca + lane; j0 < cb + lane; j0 += kHeavyRows * kWave) {  // wavefront-uniform trip count
+          uint2 e[kHeavyRows];
+          uint32_t idv[kHeavyRows];
+#pragma unroll
+          for (uint32_t r = 0; r < kHeavyRows; ++r) {
+            const uint32_t j = j0 + r * kWave;
+            if (j < cb) {
+              e[r] = v.se[j];
+              idv[r] = v.id[j];
+            }
           }
-          written += (uint32_t)__popcll(m);
+#pragma unroll
+          for (uint32_t r = 0; r < kHeavyRows; ++r) {
+            const uint32_t j = j0 + r * kWave;
+            const bool hit = j < cb && e[r].x <= ch && e[r].y >= cl &&
+                             (!F || filter_accept(v, cl, ch, cx, e[r].x, e[r].y, idv[r]));
+            const uint64_t m = __ballot(hit);
+            if (hit) {
+              const uint64_t p = pos0 + written + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+              if (p < cap) hits_base[p] = idv[r];
+            }
+            written += (uint32_t)__popcll(m);
+          }
         }
         if (lane == src) acc += written;
       }
@@ -679,7 +707,7 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   for (int r = 0; r < kFR; ++r) qy[r] = load_query<F>(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
 #pragma unroll
   for (int r = 0; r < kFR; ++r) {
-    cnt[r] = enumerate_hits<Mode::Count, F, MS>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
+    cnt[r] = enumerate_hits<Mode::Count, F, MS, MS ? kRowsWide : kRowsLean>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
                                              reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x]),
                                              reinterpret_cast<uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]));
     tsum += cnt[r];
@@ -852,7 +880,8 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
         });
         qy[r].nseg = 0;
       }
-      if (!all_replay) (void)enumerate_hits<Mode::Fill, F>(v, segs, qy[r], hits, pos, cap, nullptr);
+      if (!all_replay)
+        (void)enumerate_hits<Mode::Fill, F, false, MS ? kRowsWide : kRowsLean>(v, segs, qy[r], hits, pos, cap, nullptr);
       if (S) {  // a wavefront with general-path queries: sort what it has just written (lists cut by `cap` stay cut)
         wave_sync_mem();
         const uint64_t e = pos + cnt[r];
