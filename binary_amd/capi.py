@@ -10,14 +10,14 @@ import os
 from ._build import LIB_PATH
 
 BIVX_NO_HIT = 0xFFFFFFFF
-ABI_VERSION = 0x00010002
+ABI_VERSION = 0x00010003
 
 EXPORTS = (
     "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_destroy", "bivx_device", "bivx_append",
     "bivx_append_dev", "bivx_clear", "bivx_build", "bivx_is_built", "bivx_size", "bivx_num_chroms",
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_workspace_bytes", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
-    "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f", "bivx_query_dev_s",
+    "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f", "bivx_query_dev_s", "bivx_query_dev_u",
     "bivx_find_overlaps", "bivx_free",
 )
 
@@ -95,6 +95,7 @@ def load() -> C.CDLL:
     L.bivx_fill_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, vp]
     L.bivx_query_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, C.c_uint64, vp, sz, vp]
     L.bivx_query_dev_s.argtypes = [vp, u32p, u32p, u32p, sz, fp, C.c_int, u64p, u32p, C.c_uint64, vp, sz, vp]
+    L.bivx_query_dev_u.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, u32p, C.c_uint64, u64p, vp, sz, vp]
     if L.bivx_abi_version() >> 16 != ABI_VERSION >> 16:
         raise ImportError("libbivx.so ABI major version mismatch")
     _lib = L

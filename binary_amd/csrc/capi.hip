@@ -614,18 +614,21 @@ int bivx_query_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint
                           workspace_bytes, stream);
 }
 
-int bivx_query_dev_s(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
-                     size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *d_offsets, uint32_t *d_hit_ids,
-                     uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes, void *stream) {
-  BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, "bivx_query_dev"));
+namespace {
+// the single-pass entry points; d_counts != nullptr selects the unordered begin/count output
+int query_single_pass(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                      size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *d_offsets, uint32_t *d_counts,
+                      uint32_t *d_hit_ids, uint64_t hit_capacity, uint64_t *d_total, void *d_workspace,
+                      size_t workspace_bytes, void *stream, const char *who) {
+  BIVX_TRY(check_query_args(idx, d_qlow, d_qhigh, q, who));
   IndexView view;
   BIVX_TRY(view_with_filter(idx, filter, view));
-  if (!d_offsets || (hit_capacity && !d_hit_ids)) {
-    set_error("bivx_query_dev: null argument");
+  if ((q && !d_offsets) || (!d_counts && !d_offsets) || (hit_capacity && !d_hit_ids)) {
+    set_error("%s: null argument", who);
     return BIVX_E_INVALID;
   }
   if (d_workspace && workspace_bytes < fused_workspace_bytes(q)) {
-    set_error("bivx_query_dev: workspace too small (%zu < %zu)", workspace_bytes, fused_workspace_bytes(q));
+    set_error("%s: workspace too small (%zu < %zu)", who, workspace_bytes, fused_workspace_bytes(q));
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
@@ -644,7 +647,28 @@ int bivx_query_dev_s(const bivx_index *idx, const uint32_t *d_qchrom, const uint
     self_clean = true;
   }
   return launch_query_fused(view, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, hit_capacity, d_workspace,
-                            self_clean, sort_by_id != 0, s);
+                            self_clean, sort_by_id != 0, s, d_counts, d_total);
+}
+}  // namespace
+
+int bivx_query_dev_s(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                     size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *d_offsets, uint32_t *d_hit_ids,
+                     uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes, void *stream) {
+  return query_single_pass(idx, d_qchrom, d_qlow, d_qhigh, q, filter, sort_by_id, d_offsets, nullptr, d_hit_ids,
+                           hit_capacity, nullptr, d_workspace, workspace_bytes, stream, "bivx_query_dev");
+}
+
+int bivx_query_dev_u(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                     size_t q, const bivx_filter *filter, uint64_t *d_begin, uint32_t *d_count, uint32_t *d_hit_ids,
+                     uint64_t hit_capacity, uint64_t *d_total, void *d_workspace, size_t workspace_bytes,
+                     void *stream) {
+  if (!d_total || (q && !d_count)) {
+    set_error("bivx_query_dev_u: null argument");
+    return BIVX_E_INVALID;
+  }
+  uint32_t dummy = 0;
+  return query_single_pass(idx, d_qchrom, d_qlow, d_qhigh, q, filter, 0, d_begin, q ? d_count : &dummy, d_hit_ids,
+                           hit_capacity, d_total, d_workspace, workspace_bytes, stream, "bivx_query_dev_u");
 }
 
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q, void *stream) {

@@ -114,6 +114,7 @@ size_t fused_workspace_bytes(size_t q);
 size_t fused_workspace_timeouts_offset();  // byte offset of the "prefix wait gave up" counter inside a workspace
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
-                       void *d_ws, bool self_clean, bool sort_ids, hipStream_t s);
+                       void *d_ws, bool self_clean, bool sort_ids, hipStream_t s, uint32_t *d_counts = nullptr,
+                       uint64_t *d_total = nullptr);  // d_counts != nullptr: unordered begin/count output
 
 }  // namespace bivx

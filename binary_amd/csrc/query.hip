@@ -640,8 +640,11 @@ constexpr uint32_t kStageMin = 320;  // ... when it has at least this many (5 pe
 constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
 // on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
-constexpr uint32_t kWsTicket = 0, kWsDone = 16, kWsTimeouts = 24, kWsStatus = 32;  // kWsTimeouts is never cleared by the kernel
+constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsTimeouts = 24, kWsStatus = 32;
+// (kWsTimeouts is never cleared by the kernel)
+constexpr uint32_t kDoneShift = 44;  // unordered output: ws[kWsDone] = departures << 44 | ids reserved by this launch
 constexpr uint32_t kSpinCap = 1u << 20;
+constexpr int kFlagSelfClean = 1, kFlagFinal = 2;  // k_query_fused flags: index-owned workspace; last launch of the call
 
 __device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -663,13 +666,20 @@ __device__ unsigned long long g_stamps[kFMaxTiles * 8];
 // two workgroups per CU (8 waves per SIMD): keeps the kernel within 64 VGPRs.
 // S: every query's ids leave in ascending order (sorted on their way through the output stage; no second pass).
 // MS: the index has chromosomes with several segments; queries record up to kMaxRec windows for the replay.
-template <bool LDS_DESC, bool F, bool S, bool MS>
+// U: unordered output (bivx_query_dev_u). A tile reserves its output range with ONE atomic add on a running
+//    total and waits for nobody: no ticket, no status words, no prefix sweep. `offsets` then receives begin[q]
+//    (q words) and `counts` count[q]; ranges of different tiles lie in the buffer in whatever order the tiles
+//    got there, inside a tile they are in query order. The last tile to leave stores the total in *total_out.
+template <bool LDS_DESC, bool F, bool S, bool MS, bool U>
 __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThreads / 256)) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
                                                            const uint32_t *__restrict__ qhigh, size_t q_begin,
                                                            size_t q_end, uint64_t *__restrict__ offsets,
                                                            uint32_t *__restrict__ hits, uint64_t cap,
-                                                           uint64_t *__restrict__ ws, int self_clean) {
+                                                           uint64_t *__restrict__ ws, int flags,
+                                                           uint32_t *__restrict__ counts,
+                                                           uint64_t *__restrict__ total_out) {
+  const bool self_clean = (flags & kFlagSelfClean) != 0;
   __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
   __shared__ uint32_t s_cs[LDS_DESC ? kLdsChroms + 1 : 1];
   __shared__ uint32_t s_tile;
@@ -684,11 +694,10 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
 
   BIVX_STAMP(0);
   if (threadIdx.x == 0) s_last = 0;
-#ifdef BIVX_NO_TICKET  // timing experiment only: relies on in-order dispatch, which HIP does not promise
-  if (threadIdx.x == 0) s_tile = blockIdx.x;
-#else
-  if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTicket), 1u);
-#endif
+  // ordered output: tiles take tickets, so that every predecessor of a waiting tile is resident.
+  // unordered output: tiles never wait for each other, any tile may be any block.
+  if (threadIdx.x == 0)
+    s_tile = U ? blockIdx.x : atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTicket), 1u);
   const SegDesc *segs;
   const uint32_t *cs;
   stage_descriptors<LDS_DESC>(v, s_seg, s_cs, segs, cs);
@@ -733,7 +742,10 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   const uint32_t local = wbase + incl - tsum;
 
   // prefix across tiles: wave 0 publishes this tile's total and sums every earlier tile's
-  if (wave == 0) {
+  if (U) {
+    if (threadIdx.x == 0)
+      s_base = atomicAdd(reinterpret_cast<unsigned long long *>(ws + kWsTicket), (unsigned long long)total);
+  } else if (wave == 0) {
     BIVX_STAMP(3);
     if (lane == 0) st_status(&status[tile], kStValid | (uint64_t)total);
     uint64_t sum = 0;
@@ -776,7 +788,8 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
     const size_t q = q0 + r;
     if (q < q_end) {
       offsets[q] = pos;
-      if (q == q_end - 1) offsets[q_end] = pos + cnt[r];
+      if (U) counts[q] = cnt[r];
+      else if (q == q_end - 1) offsets[q_end] = pos + cnt[r];
     }
     const uint32_t *kept = reinterpret_cast<const uint32_t *>(&s_keep[r][threadIdx.x]);
     // The replay cursor walks the lane's recorded windows in segment order: `mrem` holds the bits of the current
@@ -893,13 +906,34 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   // self-cleaning workspace: every tile bumps `done` when it leaves (its sweep is long over); the tile that
   // sees gridDim.x - 1 knows nobody reads the words any more and zeroes them for the next launch. Off the
   // critical path: nothing waits for this but the end of the kernel.
-  if (self_clean) {
-    if (threadIdx.x == 0 && atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1) s_last = 1;
+  // Unordered output finds the last tile with the same word, and sums the tiles' totals in it on the way (one
+  // atomic carries both: departures in the high bits, ids in the low kDoneShift bits), so the last tile knows the
+  // launch total without reading a word other tiles are still adding to — no fence anywhere: an agent-scope fence
+  // writes back and invalidates the XCD's whole L2 on this chip, which cost more than the prefix it replaced.
+  if (self_clean || U) {
+    if (threadIdx.x == 0) {
+      if (U) {
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(ws + kWsDone),
+                                                 (1ull << kDoneShift) | (unsigned long long)total);
+        if ((old >> kDoneShift) == gridDim.x - 1) {
+          s_last = 1;
+          s_base = (old & ((1ull << kDoneShift) - 1)) + total;  // ids reserved by this launch
+        }
+      } else if (atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1) {
+        s_last = 1;
+      }
+    }
     __syncthreads();
     if (s_last) {
-      for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) status[t] = 0;
+      if (!U)
+        for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) status[t] = 0;
       if (threadIdx.x == 0) {
-        ws[kWsTicket] = 0;
+        if (U) {  // running total over the call's launches; the reservation counter restarts after the last one
+          const uint64_t sum = ws[kWsCarry] + s_base;
+          *total_out = sum;
+          ws[kWsCarry] = (flags & kFlagFinal) ? 0 : sum;
+        }
+        if (!U || (flags & kFlagFinal)) ws[kWsTicket] = 0;
         ws[kWsDone] = 0;
       }
     }
@@ -957,32 +991,44 @@ size_t fused_workspace_timeouts_offset() { return (size_t)kWsTimeouts * sizeof(u
 
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
-                       void *d_ws, bool self_clean, bool sort_ids, hipStream_t s) {
+                       void *d_ws, bool self_clean, bool sort_ids, hipStream_t s, uint32_t *d_counts,
+                       uint64_t *d_total) {
+  const bool unordered = d_counts != nullptr;  // begin/count output, see k_query_fused
   if (q == 0) {
-    BIVX_HIP(hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), s));
+    BIVX_HIP(hipMemsetAsync(unordered ? d_total : d_offsets, 0, sizeof(uint64_t), s));
     return 0;
   }
   uint64_t *ws = static_cast<uint64_t *>(d_ws);
   const size_t per_launch = (size_t)kFMaxTiles * kFTile;
+  // caller's workspace: zeroed in front of every launch (ordered output), or once per call (unordered output:
+  // the running total lives in it across the call's launches)
+  if (!self_clean && unordered) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));
   for (size_t q0 = 0; q0 < q; q0 += per_launch) {
     const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
     const unsigned tiles = (unsigned)((q1 - q0 + kFTile - 1) / kFTile);
-    // ticket, done counter, status words: zeroed here, or left zeroed by the previous launch (self_clean)
-    if (!self_clean) BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kWsStatus) * sizeof(uint64_t), s));
+    if (!self_clean && !unordered)
+      BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kWsStatus) * sizeof(uint64_t), s));
     const dim3 grid(tiles), block(kFThreads);
     const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
-    const int sc = self_clean ? 1 : 0;
+    const int flags = (self_clean ? kFlagSelfClean : 0) | (q1 == q ? kFlagFinal : 0);
     // Ordering ids inside the kernel pays while a wavefront's 64 lists fit half its output stage (one round, all
     // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
     // ordered by k_sort_hits afterwards, whose stage is eight times larger.
-    const bool sort_inside = sort_ids && cap <= (uint64_t)kFusedSortMaxAvg * q;
-#define BIVX_LAUNCH_FUSED(L, FL, SO)                                                                           \
-  if (v.max_segs > 1)                                                                                              \
-    hipLaunchKernelGGL((k_query_fused<L, FL, SO, true>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, \
-                       d_offsets, d_hits, cap, ws, sc);                                                            \
-  else                                                                                                             \
-    hipLaunchKernelGGL((k_query_fused<L, FL, SO, false>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, q1, \
-                       d_offsets, d_hits, cap, ws, sc)
+    const bool sort_inside = sort_ids && !unordered && cap <= (uint64_t)kFusedSortMaxAvg * q;
+#define BIVX_LAUNCH_FUSED_V(L, FL, SO, MSV, UV)                                                               \
+  hipLaunchKernelGGL((k_query_fused<L, FL, SO, MSV, UV>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, \
+                     q1, d_offsets, d_hits, cap, ws, flags, d_counts, d_total)
+#define BIVX_LAUNCH_FUSED(L, FL, SO)                       \
+  if (unordered) {                                         \
+    if (v.max_segs > 1)                                    \
+      BIVX_LAUNCH_FUSED_V(L, FL, false, true, true);       \
+    else                                                   \
+      BIVX_LAUNCH_FUSED_V(L, FL, false, false, true);      \
+  } else if (v.max_segs > 1) {                             \
+    BIVX_LAUNCH_FUSED_V(L, FL, SO, true, false);           \
+  } else {                                                 \
+    BIVX_LAUNCH_FUSED_V(L, FL, SO, false, false);          \
+  }
     switch ((lds ? 4 : 0) | (flt ? 2 : 0) | (sort_inside ? 1 : 0)) {
       case 0: BIVX_LAUNCH_FUSED(false, false, false); break;
       case 1: BIVX_LAUNCH_FUSED(false, false, true); break;
@@ -994,7 +1040,8 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
       default: BIVX_LAUNCH_FUSED(true, true, true); break;
     }
 #undef BIVX_LAUNCH_FUSED
-    if (sort_ids && !sort_inside) {
+#undef BIVX_LAUNCH_FUSED_V
+    if (sort_ids && !sort_inside && !unordered) {
       BIVX_HIP(hipGetLastError());
       if (int rc = launch_sort_hits(d_offsets + q0, d_hits, q1 - q0, cap, s)) return rc;
     }

@@ -224,6 +224,30 @@ class IntervalIndex:
                                             0 if workspace is None else workspace.numel(), s))
         return offsets, hits
 
+    def query_device_unordered(self, qlow, qhigh, begin, count, hits, total, workspace=None, qchrom=None, flt=None):
+        """Single pass without the canonical CSR (bivx_query_dev_u); asynchronous. Query i's hits are
+        hits[begin[i] : begin[i] + count[i]] (index order); workgroups reserve their output ranges in arrival
+        order, so the layout differs from call to call while the sets do not. total (int64[1]) receives the number
+        of ids reserved; if it exceeds hits.numel() only a prefix of the buffer was written."""
+        self._ensure_built()
+        q = qlow.numel()
+        _check_dev_tensor(qlow, "qlow")
+        _check_dev_tensor(qhigh, "qhigh", q)
+        if qchrom is not None:
+            _check_dev_tensor(qchrom, "qchrom", q)
+        _check_dev_tensor(begin, "begin", q, 8)
+        _check_dev_tensor(count, "count", q)
+        _check_dev_tensor(hits, "hits")
+        _check_dev_tensor(total, "total", 1, 8)
+        if workspace is not None:
+            _check_dev_tensor(workspace, "workspace", None, 1)
+        s = C.c_void_p(torch.cuda.current_stream(qlow.device).cuda_stream)
+        capi.check(self._L.bivx_query_dev_u(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q,
+                                            None if flt is None else C.byref(flt), _tptr(begin), _tptr(count),
+                                            _tptr(hits), hits.numel(), _tptr(total), _tptr(workspace),
+                                            0 if workspace is None else workspace.numel(), s))
+        return begin, count, hits, total
+
     def find_overlaps_device(self, qlow, qhigh, qchrom=None, sort_by_id: bool = False):
         """(offsets int64[q+1], hits int32[H]) as device tensors. One host sync to size the hit buffer."""
         offsets = self.count_overlaps_device(qlow, qhigh, qchrom)

@@ -521,3 +521,63 @@ def test_single_pass_over_several_length_classes(IntervalIndex, oracle, max_len)
     off_o, hits_o = t.find_overlaps_batch(qlo, qhi)
     assert np.array_equal(ref_off, off_o.astype(np.uint64))
     assert np.array_equal(got.astype(np.int64), oracle.sorted_csr(off_o, hits_o))
+
+
+def _check_unordered(begin, count, hits, total, ref_off, ref_hits_sorted, cap):
+    """begin/count output against an id-sorted reference CSR: same sets, disjoint ranges, exact total."""
+    begin, count = begin.astype(np.int64), count.astype(np.int64)
+    ref_cnt = np.diff(ref_off.astype(np.int64))
+    assert np.array_equal(count, ref_cnt)
+    assert total == int(ref_cnt.sum())
+    nz = count > 0
+    o = np.argsort(begin[nz], kind="stable")
+    b, c = begin[nz][o], count[nz][o]
+    assert b.size == 0 or (b[0] == 0 and np.array_equal(b[1:], (b + c)[:-1]))   # the ranges tile [0, total) exactly
+    if total <= cap:
+        idx = np.repeat(begin - np.cumsum(count) + count, count) + np.arange(int(count.sum()))
+        got = hits[idx]                                   # lists gathered in query order
+        seg = np.repeat(np.arange(count.size), count)
+        order = np.lexsort((got, seg))
+        assert np.array_equal(got[order].astype(np.int64), ref_hits_sorted.astype(np.int64))
+
+
+@pytest.mark.parametrize("nq", [1, 1000, 1024, 70_001, 1_300_003])
+def test_unordered_single_pass_same_sets(IntervalIndex, nq):
+    """bivx_query_dev_u: per-query (begin, count) instead of a CSR; sets, counts and the total must be those of the
+    ordered paths, ranges must tile the buffer, repeated calls and both workspace kinds must agree, and a buffer
+    that is too small is never overrun."""
+    import torch
+    from binary_amd import synth
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    data = synth.gen_genome(200_000, nq, 1000)
+    rng = np.random.default_rng(nq)
+    data["high"][:30] = data["low"][:30] + rng.integers(1_000_000, 50_000_000, size=30).astype(np.uint32)  # classes
+    if nq > 100:
+        data["qhigh"][:20] = data["qlow"][:20] + rng.integers(100_000, 5_000_000, size=20).astype(np.uint32)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(data["low"], data["high"], data["chrom"])
+        idx.build()
+        ref_off, ref_hits = idx.find_overlaps(data["qlow"], data["qhigh"], data["qchrom"], sort_by_id=True)
+        H = int(ref_off[-1])
+        ql, qh, qc = to(data["qlow"]), to(data["qhigh"]), to(data["qchrom"])
+        guard = 1024
+        for rep, (cap, own_ws) in enumerate([(H, False), (H, True), (H + 77, False), (H // 2, False), (0, True)]):
+            begin = torch.empty(nq, dtype=torch.int64, device=dev)
+            count = torch.empty(nq, dtype=torch.int32, device=dev)
+            total = torch.full((1,), -1, dtype=torch.int64, device=dev)
+            buf = torch.full((cap + guard,), -2, dtype=torch.int32, device=dev)
+            ws = torch.empty(idx.query_workspace_bytes(nq), dtype=torch.uint8, device=dev) if own_ws else None
+            for _ in range(2):
+                idx.query_device_unordered(ql, qh, begin, count, buf[:cap], total, workspace=ws, qchrom=qc)
+            torch.cuda.synchronize()
+            assert bool((buf[cap:] == -2).all())
+            _check_unordered(begin.cpu().numpy(), count.cpu().numpy(), buf[:cap].cpu().numpy().view(np.uint32),
+                             int(total.item()), ref_off, ref_hits, cap)
+        # the ordered single pass still works on the same stream afterwards (they share the index's workspace)
+        off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        hits = torch.empty(max(H, 1), dtype=torch.int32, device=dev)
+        idx.query_device(ql, qh, off, hits, qchrom=qc, sort_by_id=True)
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), ref_off)
+        assert np.array_equal(hits.cpu().numpy().view(np.uint32)[:H], ref_hits)
+        assert idx.stats()["prefix_timeouts"] == 0

@@ -58,8 +58,14 @@ def run_config(name, data, reps):
         ms2 = timed(lambda: (idx.count_overlaps_device(ql, qh, qc, offsets=off, workspace=ws),
                              idx.fill_overlaps_device(ql, qh, off, hits, qchrom=qc)), reps)
         ms3 = timed(lambda: idx.query_device(ql, qh, off, hits, qws, qchrom=qc, sort_by_id=True), reps)
+        beg = torch.empty(Q, dtype=torch.int64, device=dev)
+        cnt = torch.empty(Q, dtype=torch.int32, device=dev)
+        tot = torch.zeros(1, dtype=torch.int64, device=dev)
+        ms4 = timed(lambda: idx.query_device_unordered(ql, qh, beg, cnt, hits, tot, qchrom=qc), reps)
+        assert int(tot.item()) == H
         b_alg = 8 * data["low"].size + 8 * Q + 8 * (Q + 1) + 4 * H
         out[order] = {"hits": H, "single_pass_ms": ms1, "two_pass_ms": ms2, "single_pass_sorted_ids_ms": ms3,
+                      "unordered_begin_count_ms": ms4, "unordered_gqps": Q / ms4 / 1e6,
                       "single_pass_gqps": Q / ms1 / 1e6, "algorithmic_gbs": b_alg / ms1 / 1e6,
                       "algorithmic_frac_of_8tbs": b_alg / ms1 / 1e6 / 8000.0}
     # host-pointer API: upload queries, count, download offsets, fill, download hits (PCIe inclusive)
