@@ -686,6 +686,7 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   __shared__ uint32_t s_last;  // this tile finished its prefix sweep last: it zeroes the workspace for the next call
   __shared__ uint32_t s_wsum[kFWaves];
   __shared__ uint64_t s_base;
+  __shared__ uint64_t s_launch_total;  // unordered output, last tile only
   __shared__ uint4 s_keep[kFR][kFThreads];  // ids of each query's first kKeep hits (thread-private slots)
   __shared__ uint32_t s_out[kFWaves][kStage];  // per-wavefront staging of the output ids
   __shared__ uint4 s_xrec[MS ? kFThreads : 1];  // a query's third recorded window (thread-private slots)
@@ -917,7 +918,7 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
                                                  (1ull << kDoneShift) | (unsigned long long)total);
         if ((old >> kDoneShift) == gridDim.x - 1) {
           s_last = 1;
-          s_base = (old & ((1ull << kDoneShift) - 1)) + total;  // ids reserved by this launch
+          s_launch_total = (old & ((1ull << kDoneShift) - 1)) + total;  // ids reserved by this launch
         }
       } else if (atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1) {
         s_last = 1;
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
         for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) status[t] = 0;
       if (threadIdx.x == 0) {
         if (U) {  // running total over the call's launches; the reservation counter restarts after the last one
-          const uint64_t sum = ws[kWsCarry] + s_base;
+          const uint64_t sum = ws[kWsCarry] + s_launch_total;
           *total_out = sum;
           ws[kWsCarry] = (flags & kFlagFinal) ? 0 : sum;
         }
