@@ -613,14 +613,17 @@ __global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restr
 // ---- single-pass kernel ----------------------------------------------------------------------------------
 // A workgroup owns kFTile = 1024 consecutive queries. It counts them (remembering each short window's hit
 // mask and the ids of its first hits), publishes its hit total, sums the totals of ALL earlier tiles, then
-// writes offsets and hit ids. One launch has at most kFMaxTiles tiles, so the prefix is a sweep over at most 1023 status words
-// (16 loads per lane, issued four at a time) instead of a serial look-back chain: on MI355X every poll of
-// another XCD's status word goes to memory (per-XCD L2s are not coherent), so the number of dependent polls,
-// not their width, is what costs. Larger batches run as consecutive launches; each starts from the running
-// total its predecessor left in offsets[q_begin].
-//   ws[kWsTicket] (low 32 bits): tile ticket. ws[kWsDone]: tiles that have left. ws[kWsStatus + t]: kStValid |
-//   hits of tile t, written and polled as ONE 8-byte
-//   agent-scope atomic, so the value needs no separate fence. Tiles take tickets in launch order: every
+// writes offsets and hit ids. The prefix is a two-level sweep, not a serial look-back chain: on MI355X every
+// poll of another XCD's status word goes to memory (per-XCD L2s are not coherent), so the number of dependent
+// polls, not their width, is what costs. Tiles form groups of 64. A tile reads the words of the earlier tiles of
+// its group (one load per lane) and the words of all earlier GROUPS (one load per lane up to 64 groups, i.e.
+// 4 M queries; four in flight beyond); the 64th tile of a group publishes the group's total as soon as it has
+// its in-group sum. So a tile waits for at most two levels, and one launch covers up to kFMaxTiles tiles (64 M
+// queries). Larger batches run as consecutive launches; each starts from the running total its predecessor left
+// in offsets[q_begin].
+//   ws[kWsTicket] (low 32 bits): tile ticket. ws[kWsDone]: tiles that have left. ws[kWsStatus + g]: kStValid |
+//   hits of group g; ws[kWsStatus + kFMaxGroups + t]: kStValid | hits of tile t. Each is written and polled as ONE
+//   8-byte agent-scope atomic, so the value needs no separate fence. Tiles take tickets in launch order: every
 //   predecessor of a polling tile is already resident, the wait cannot deadlock; spins are bounded anyway.
 #ifndef BIVX_FUSED_THREADS
 #define BIVX_FUSED_THREADS 1024
@@ -630,7 +633,9 @@ constexpr int kFWaves = kFThreads / kWave;
 constexpr int kFR = 1;  // queries per thread. (More per thread was measured and did not pay: a wavefront here is
                         // latency-bound, and the output staging below assumes the 64 lists of a wavefront are adjacent.)
 constexpr int kFTile = kFThreads * kFR;
-constexpr unsigned kFMaxTiles = 1024;
+constexpr unsigned kFMaxTiles = 65536;                 // tiles per launch (ordered output)
+constexpr unsigned kFMaxGroups = kFMaxTiles / kWave;   // groups of 64 tiles
+constexpr unsigned kFlatTiles = 1024;                  // launches up to this many tiles sweep the tile words directly
 constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per round before streaming them out
 #ifndef BIVX_GATHER
 #define BIVX_GATHER 8
@@ -656,14 +661,15 @@ __device__ __forceinline__ void st_status(uint64_t *p, uint64_t w) {
 // Diagnostic build only (-DBIVX_STAMPS): per-tile wall-clock stamps (100 MHz constant counter) written to a
 // buffer no other code reads; the product build has no stamp.
 #ifdef BIVX_STAMPS
-__device__ unsigned long long g_stamps[kFMaxTiles * 8];
+constexpr unsigned kStampTiles = 1024;
+__device__ unsigned long long g_stamps[kStampTiles * 8];
 #define BIVX_STAMP(k) \
-  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kFMaxTiles) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kStampTiles) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
 #else
 #define BIVX_STAMP(k)
 #endif
 
-// two workgroups per CU (8 waves per SIMD): keeps the kernel within 64 VGPRs.
+// 8 waves per SIMD (two workgroups of 1024 threads per CU): keeps the kernel within 64 VGPRs.
 // S: every query's ids leave in ascending order (sorted on their way through the output stage; no second pass).
 // MS: the index has chromosomes with several segments; queries record up to kMaxRec windows for the replay.
 // U: unordered output (bivx_query_dev_u). A tile reserves its output range with ONE atomic add on a running
@@ -671,7 +677,7 @@ __device__ unsigned long long g_stamps[kFMaxTiles * 8];
 //    (q words) and `counts` count[q]; ranges of different tiles lie in the buffer in whatever order the tiles
 //    got there, inside a tile they are in query order. The last tile to leave stores the total in *total_out.
 template <bool LDS_DESC, bool F, bool S, bool MS, bool U>
-__global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThreads / 256)) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
+__global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
                                                            const uint32_t *__restrict__ qhigh, size_t q_begin,
                                                            size_t q_end, uint64_t *__restrict__ offsets,
@@ -704,8 +710,11 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   stage_descriptors<LDS_DESC>(v, s_seg, s_cs, segs, cs);
   __syncthreads();
   const uint32_t tile = s_tile;
-  uint64_t *status = ws + kWsStatus;
+  uint64_t *group = ws + kWsStatus, *status = group + kFMaxGroups;
   BIVX_STAMP(1);
+  // A ticket beyond the grid means the workspace was not zeroed (a caller bug): leave without touching memory
+  // rather than index the status array and the queries with it.
+  if (tile >= gridDim.x) return;
 
   // phase 1: count the thread's kFR consecutive queries
   const size_t q0 = q_begin + ((size_t)tile * kFThreads + threadIdx.x) * kFR;
@@ -749,28 +758,49 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   } else if (wave == 0) {
     BIVX_STAMP(3);
     if (lane == 0) st_status(&status[tile], kStValid | (uint64_t)total);
+    auto wait_word = [&](const uint64_t *p, uint64_t w) -> uint64_t {
+      uint32_t spins = 0;
+      while (!(w & kStValid) && spins < kSpinCap) {  // bounded: a wrong prefix beats a hung GPU
+        __builtin_amdgcn_s_sleep(1);
+        w = ld_status(p);
+        ++spins;
+      }
+      if (!(w & kStValid)) atomicAdd(reinterpret_cast<unsigned long long *>(ws + kWsTimeouts), 1ull);
+      return w & ~kStValid;
+    };
+    auto wave_total = [&](uint64_t x) -> uint64_t {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) x += __shfl_xor((unsigned long long)x, d, kWave);
+      return x;
+    };
+    // Launches of up to kFlatTiles tiles (1 M queries) sweep the tile words directly, one level: measured 3 us
+    // faster there than two levels, whose second level is one more dependent round trip. Larger launches go
+    // through the groups: the earlier tiles of this tile's group (one word per lane), then all earlier groups.
+    const bool flat = gridDim.x <= kFlatTiles;
+    const uint32_t g = tile >> 6, r = tile & 63u;
+    uint64_t in_group = 0;
+    if (!flat) {
+      const uint64_t *mine = &status[(g << 6) + (uint32_t)lane];
+      in_group = wave_total((uint32_t)lane < r ? wait_word(mine, ld_status(mine)) : 0ull);
+      if (r == 63u && lane == 0) st_status(&group[g], kStValid | (in_group + total));
+    }
+    const uint64_t *words = flat ? status : group;
+    const uint32_t nwords = flat ? tile : g;
     uint64_t sum = 0;
-    for (uint32_t t0 = 0; t0 < tile; t0 += 4 * kWave) {
+    for (uint32_t t0 = 0; t0 < nwords; t0 += 4 * kWave) {
       uint64_t w[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t t = t0 + j * kWave + lane;
-        w[j] = t < tile ? ld_status(&status[t]) : kStValid;
+        w[j] = t < nwords ? ld_status(&words[t]) : kStValid;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t t = t0 + j * kWave + lane;
-        uint32_t spins = 0;
-        while (!(w[j] & kStValid) && spins < kSpinCap) {  // bounded: a wrong prefix beats a hung GPU
-          __builtin_amdgcn_s_sleep(1);
-          w[j] = ld_status(&status[t]);
-          ++spins;
-        }
-        sum += w[j] & ~kStValid;
+        sum += t < nwords ? wait_word(&words[t], w[j]) : 0ull;
       }
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor((unsigned long long)sum, d, kWave);
+    sum = wave_total(sum) + in_group;
     if (lane == 0) s_base = sum + (q_begin ? offsets[q_begin] : 0ull);
     BIVX_STAMP(4);
   }
@@ -843,7 +873,9 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
     const uint64_t wpos0 = __shfl((unsigned long long)pos, 0, kWave);
     const uint32_t loff = (uint32_t)(pos - wpos0);
     const uint32_t wtotal = __shfl(loff + cnt[r], kWave - 1, kWave);
-    if (S && all_replay) {
+    if (cap == 0) {
+      // a pure count (bivx_count_dev): the offsets are all that is asked for
+    } else if (S && all_replay) {
       // Rounds of consecutive lanes whose lists fit half the stage together (a list has at most kLight ids): ids
       // go to one half in slot order, every lane rank-sorts its own list into the other half, and that half is
       // streamed out coalesced.
@@ -927,7 +959,10 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
     __syncthreads();
     if (s_last) {
       if (!U)
-        for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) status[t] = 0;
+        for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) {
+          status[t] = 0;
+          if (t < (gridDim.x + kWave - 1) / kWave) group[t] = 0;
+        }
       if (threadIdx.x == 0) {
         if (U) {  // running total over the call's launches; the reservation counter restarts after the last one
           const uint64_t sum = ws[kWsCarry] + s_launch_total;
@@ -941,7 +976,7 @@ __global__ __launch_bounds__(kFThreads, (2 * kFThreads / 256 > 8 ? 8 : 2 * kFThr
   }
   BIVX_STAMP(6);
 #ifdef BIVX_STAMPS
-  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kFMaxTiles) * 8 + 7] = tile;
+  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kStampTiles) * 8 + 7] = tile;
 #endif
 }
 
@@ -968,11 +1003,6 @@ int launch_query(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d
 
 }  // namespace
 
-int launch_count(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
-                 size_t q, uint32_t *d_counts, hipStream_t s) {
-  return launch_query<Mode::Count>(v, d_qchrom, d_qlow, d_qhigh, q, nullptr, d_counts, s);
-}
-
 int launch_fill(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                 size_t q, const uint64_t *d_offsets, uint32_t *d_hits, hipStream_t s) {
   return launch_query<Mode::Fill>(v, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hits, s);
@@ -985,7 +1015,7 @@ int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_q
 
 size_t fused_workspace_bytes(size_t q) {
   (void)q;
-  return ((size_t)kFMaxTiles + kWsStatus) * sizeof(uint64_t);
+  return ((size_t)kFMaxTiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t);
 }
 
 size_t fused_workspace_timeouts_offset() { return (size_t)kWsTimeouts * sizeof(uint64_t); }
@@ -1000,7 +1030,9 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     return 0;
   }
   uint64_t *ws = static_cast<uint64_t *>(d_ws);
-  const size_t per_launch = (size_t)kFMaxTiles * kFTile;
+  // ordered output: a launch is limited to the tiles one prefix sweep covers; unordered output has no such limit
+  // (only the departure count's 20 bits in ws[kWsDone])
+  const size_t per_launch = (size_t)(unordered ? (1u << 19) : kFMaxTiles) * kFTile;
   // caller's workspace: zeroed in front of every launch (ordered output), or once per call (unordered output:
   // the running total lives in it across the call's launches)
   if (!self_clean && unordered) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));
@@ -1008,7 +1040,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
     const unsigned tiles = (unsigned)((q1 - q0 + kFTile - 1) / kFTile);
     if (!self_clean && !unordered)
-      BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kWsStatus) * sizeof(uint64_t), s));
+      BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
     const dim3 grid(tiles), block(kFThreads);
     const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
     const int flags = (self_clean ? kFlagSelfClean : 0) | (q1 == q ? kFlagFinal : 0);
@@ -1053,7 +1085,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
 
 #ifdef BIVX_STAMPS
 extern "C" int bivx_debug_stamps(unsigned long long *out, size_t n) {
-  if (n > (size_t)kFMaxTiles * 8) n = (size_t)kFMaxTiles * 8;
+  if (n > (size_t)kStampTiles * 8) n = (size_t)kStampTiles * 8;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -167,13 +167,10 @@ class IntervalIndex:
         if offsets is None:
             offsets = torch.empty(q + 1, dtype=torch.int64, device=qlow.device)
         _check_dev_tensor(offsets, "offsets", q + 1, 8)
-        need = int(self._L.bivx_count_workspace_bytes(q))
-        if workspace is None:
-            workspace = torch.empty(need, dtype=torch.uint8, device=qlow.device)
-        _check_dev_tensor(workspace, "workspace", None, 1)
+        # `workspace` is accepted for compatibility; bivx_count_dev needs no caller scratch since ABI 1.3
         s = torch.cuda.current_stream(qlow.device).cuda_stream
         capi.check(self._L.bivx_count_dev(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q, _tptr(offsets),
-                                          _tptr(workspace), workspace.numel(), C.c_void_p(s)))
+                                          None, 0, C.c_void_p(s)))
         return offsets
 
     def fill_overlaps_device(self, qlow, qhigh, offsets, hits, qchrom=None, sort_by_id: bool = False):

@@ -108,8 +108,9 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
                        uint32_t **hit_ids_out);
 void bivx_free(void *p);
 
-/* device-resident variants. d_workspace: bivx_count_workspace_bytes(q) bytes of scratch (NULL => the call
- * allocates and frees stream-ordered scratch itself). */
+/* device-resident variants. bivx_count_dev is one launch of the single-pass kernel with a zero-capacity hit
+ * buffer (it counts, chains the prefix across workgroups and writes d_offsets[q + 1]); since ABI 1.3 it needs no
+ * caller scratch: bivx_count_workspace_bytes returns 0 and d_workspace / workspace_bytes are ignored. */
 size_t bivx_count_workspace_bytes(size_t q);
 int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                    const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, void *d_workspace,
