@@ -77,4 +77,20 @@ def test_fuzz_against_tree_oracle(seed, oracle):
         torch.cuda.synchronize()
         assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), exp_off)
         assert np.array_equal(d_hits.cpu().numpy().view(np.uint32)[: int(exp_off[-1])], exp_hits)
+        # unordered single pass: per-query (begin, count); same sets, ranges tile the buffer, exact total
+        H = int(exp_off[-1])
+        beg = torch.empty(q, dtype=torch.int64, device=dev)
+        cnt = torch.empty(q, dtype=torch.int32, device=dev)
+        tot = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        d_hits.fill_(-1)
+        idx.query_device_unordered(to(qlo), to(qhi), beg, cnt, d_hits, tot, qchrom=to(qchrom))
+        torch.cuda.synchronize()
+        assert int(tot.item()) == H
+        b, c, hu = beg.cpu().numpy(), cnt.cpu().numpy().astype(np.int64), d_hits.cpu().numpy().view(np.uint32)
+        assert np.array_equal(c, exp_cnt.astype(np.int64))
+        nz = c > 0
+        o = np.argsort(b[nz], kind="stable")
+        assert not nz.any() or (b[nz][o][0] == 0 and np.array_equal(b[nz][o][1:], (b[nz][o] + c[nz][o])[:-1]))
+        for k in np.nonzero(nz)[0]:
+            assert np.array_equal(np.sort(hu[b[k]:b[k] + c[k]]), exp_lists[k].astype(np.uint32)), f"seed {seed}: query {k}"
         assert idx.stats()["prefix_timeouts"] == 0

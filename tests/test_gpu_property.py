@@ -81,3 +81,13 @@ def test_all_entry_points_equal_brute_force(p):
         torch.cuda.synchronize()
         assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), exp_off)
         assert np.array_equal(d_hits.cpu().numpy().view(np.uint32)[: int(exp_off[-1])], exp_hits)
+        nq = qlo.size                                                              # unordered single pass
+        beg = torch.empty(nq, dtype=torch.int64, device=dev)
+        cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+        tot = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        idx.query_device_unordered(to(qlo), to(qhi), beg, cnt, d_hits, tot, qchrom=to(qc) if use_chrom else None)
+        torch.cuda.synchronize()
+        assert int(tot.item()) == int(exp_off[-1])
+        b, c, hu = beg.cpu().numpy(), cnt.cpu().numpy(), d_hits.cpu().numpy().view(np.uint32)
+        for i in range(nq):
+            assert c[i] == exp[i].size and np.array_equal(np.sort(hu[b[i]:b[i] + c[i]]), exp[i])
