@@ -101,7 +101,7 @@ int launch_gather_intervals(const uint32_t *d_chrom, const uint32_t *d_low, cons
                             const uint32_t *d_ids, size_t n, size_t n_intervals, uint32_t *d_c, uint32_t *d_l,
                             uint32_t *d_h, hipStream_t s);
 
-// ---- query.hip --------------------------------------------------------------------------------------
+// ---- query.hip, query_fused.hip ---------------------------------------------------------------------------
 int launch_fill(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                 size_t q, const uint64_t *d_offsets, uint32_t *d_hits, hipStream_t s);
 int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,

@@ -1,0 +1,460 @@
+// query_fused.hip — the single-pass query kernel (gfx950, wave64): count, prefix across workgroups, offsets and
+// hit ids in one launch. Entry points behind it: bivx_query_dev / _f / _s (canonical CSR, optionally with ids
+// ordered inside the kernel), bivx_query_dev_u (per-query begin/count, no cross-workgroup wait) and
+// bivx_count_dev (zero-capacity buffer). Replaces a batch of IntervalTree::find_overlaps calls (reference
+// interval_tree.hpp:306-334). Device building blocks: query_device.h.
+#include "query_device.h"
+
+namespace bivx {
+namespace {
+
+// ---- single-pass kernel ----------------------------------------------------------------------------------
+// A workgroup owns kFTile = 1024 consecutive queries. It counts them (remembering each short window's hit
+// mask and the ids of its first hits), publishes its hit total, sums the totals of ALL earlier tiles, then
+// writes offsets and hit ids. The prefix is a two-level sweep, not a serial look-back chain: on MI355X every
+// poll of another XCD's status word goes to memory (per-XCD L2s are not coherent), so the number of dependent
+// polls, not their width, is what costs. Tiles form groups of 64. A tile reads the words of the earlier tiles of
+// its group (one load per lane) and the words of all earlier GROUPS (one load per lane up to 64 groups, i.e.
+// 4 M queries; four in flight beyond); the 64th tile of a group publishes the group's total as soon as it has
+// its in-group sum. So a tile waits for at most two levels, and one launch covers up to kFMaxTiles tiles (64 M
+// queries). Larger batches run as consecutive launches; each starts from the running total its predecessor left
+// in offsets[q_begin].
+//   ws[kWsTicket] (low 32 bits): tile ticket. ws[kWsDone]: tiles that have left. ws[kWsStatus + g]: kStValid |
+//   hits of group g; ws[kWsStatus + kFMaxGroups + t]: kStValid | hits of tile t. Each is written and polled as ONE
+//   8-byte agent-scope atomic, so the value needs no separate fence. Tiles take tickets in launch order: every
+//   predecessor of a polling tile is already resident, the wait cannot deadlock; spins are bounded anyway.
+#ifndef BIVX_FUSED_THREADS
+#define BIVX_FUSED_THREADS 1024
+#endif
+constexpr int kFThreads = BIVX_FUSED_THREADS;
+constexpr int kFWaves = kFThreads / kWave;
+constexpr int kFR = 1;  // queries per thread. (More per thread was measured and did not pay: a wavefront here is
+                        // latency-bound, and the output staging below assumes the 64 lists of a wavefront are adjacent.)
+constexpr int kFTile = kFThreads * kFR;
+constexpr unsigned kFMaxTiles = 65536;                 // tiles per launch (ordered output)
+constexpr unsigned kFMaxGroups = kFMaxTiles / kWave;   // groups of 64 tiles
+constexpr unsigned kFlatTiles = 1024;                  // launches up to this many tiles sweep the tile words directly
+constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per round before streaming them out
+#ifndef BIVX_GATHER
+#define BIVX_GATHER 8
+#endif
+constexpr uint32_t kGather = BIVX_GATHER;  // ids a lane fetches per step when it replays a window in phase 2
+constexpr uint32_t kStageMin = 320;  // ... when it has at least this many (5 per lane); below that lanes store directly
+constexpr uint64_t kStValid = 1ull << 63;
+// workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
+// on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
+constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsTimeouts = 24, kWsStatus = 32;
+// (kWsTimeouts is never cleared by the kernel)
+constexpr uint32_t kDoneShift = 44;  // unordered output: ws[kWsDone] = departures << 44 | ids reserved by this launch
+constexpr uint32_t kSpinCap = 1u << 20;
+constexpr int kFlagSelfClean = 1, kFlagFinal = 2;  // k_query_fused flags: index-owned workspace; last launch of the call
+
+__device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_status(uint64_t *p, uint64_t w) {
+  __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Diagnostic build only (-DBIVX_STAMPS): per-tile wall-clock stamps (100 MHz constant counter) written to a
+// buffer no other code reads; the product build has no stamp.
+#ifdef BIVX_STAMPS
+constexpr unsigned kStampTiles = 1024;
+__device__ unsigned long long g_stamps[kStampTiles * 8];
+#define BIVX_STAMP(k) \
+  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kStampTiles) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define BIVX_STAMP(k)
+#endif
+
+// 8 waves per SIMD (two workgroups of 1024 threads per CU): keeps the kernel within 64 VGPRs.
+// S: every query's ids leave in ascending order (sorted on their way through the output stage; no second pass).
+// MS: the index has chromosomes with several segments; queries record up to kMaxRec windows for the replay.
+// U: unordered output (bivx_query_dev_u). A tile reserves its output range with ONE atomic add on a running
+//    total and waits for nobody: no ticket, no status words, no prefix sweep. `offsets` then receives begin[q]
+//    (q words) and `counts` count[q]; ranges of different tiles lie in the buffer in whatever order the tiles
+//    got there, inside a tile they are in query order. The last tile to leave stores the total in *total_out.
+template <bool LDS_DESC, bool F, bool S, bool MS, bool U>
+__global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
+                                                           const uint32_t *__restrict__ qlow,
+                                                           const uint32_t *__restrict__ qhigh, size_t q_begin,
+                                                           size_t q_end, uint64_t *__restrict__ offsets,
+                                                           uint32_t *__restrict__ hits, uint64_t cap,
+                                                           uint64_t *__restrict__ ws, int flags,
+                                                           uint32_t *__restrict__ counts,
+                                                           uint64_t *__restrict__ total_out) {
+  const bool self_clean = (flags & kFlagSelfClean) != 0;
+  __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
+  __shared__ uint32_t s_cs[LDS_DESC ? kLdsChroms + 1 : 1];
+  __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_last;  // this tile finished its prefix sweep last: it zeroes the workspace for the next call
+  __shared__ uint32_t s_wsum[kFWaves];
+  __shared__ uint64_t s_base;
+  __shared__ uint64_t s_launch_total;  // unordered output, last tile only
+  __shared__ uint4 s_keep[kFR][kFThreads];  // ids of each query's first kKeep hits (thread-private slots)
+  __shared__ uint32_t s_out[kFWaves][kStage];  // per-wavefront staging of the output ids
+  __shared__ uint4 s_xrec[MS ? kFThreads : 1];  // a query's third recorded window (thread-private slots)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+
+  BIVX_STAMP(0);
+  if (threadIdx.x == 0) s_last = 0;
+  // ordered output: tiles take tickets, so that every predecessor of a waiting tile is resident.
+  // unordered output: tiles never wait for each other, any tile may be any block.
+  if (threadIdx.x == 0)
+    s_tile = U ? blockIdx.x : atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTicket), 1u);
+  const SegDesc *segs;
+  const uint32_t *cs;
+  stage_descriptors<LDS_DESC>(v, s_seg, s_cs, segs, cs);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  uint64_t *group = ws + kWsStatus, *status = group + kFMaxGroups;
+  BIVX_STAMP(1);
+  // A ticket beyond the grid means the workspace was not zeroed (a caller bug): leave without touching memory
+  // rather than index the status array and the queries with it.
+  if (tile >= gridDim.x) return;
+
+  // phase 1: count the thread's kFR consecutive queries
+  const size_t q0 = q_begin + ((size_t)tile * kFThreads + threadIdx.x) * kFR;
+  Query qy[kFR];
+  Replay rp[kFR];
+  uint32_t cnt[kFR];
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int r = 0; r < kFR; ++r) qy[r] = load_query<F>(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
+#pragma unroll
+  for (int r = 0; r < kFR; ++r) {
+    cnt[r] = enumerate_hits<Mode::Count, F, MS, MS ? kRowsWide : kRowsLean>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
+                                             reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x]),
+                                             reinterpret_cast<uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]));
+    tsum += cnt[r];
+  }
+
+  BIVX_STAMP(2);
+  // workgroup exclusive scan of the per-thread sums
+  uint32_t incl = tsum;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, kWave);
+    if (lane >= d) incl += o;
+  }
+  if (lane == kWave - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kFWaves; ++w) {
+    const uint32_t s = s_wsum[w];
+    if (w < wave) wbase += s;
+    total += s;
+  }
+  const uint32_t local = wbase + incl - tsum;
+
+  // prefix across tiles: wave 0 publishes this tile's total and sums every earlier tile's
+  if (U) {
+    if (threadIdx.x == 0)
+      s_base = atomicAdd(reinterpret_cast<unsigned long long *>(ws + kWsTicket), (unsigned long long)total);
+  } else if (wave == 0) {
+    BIVX_STAMP(3);
+    if (lane == 0) st_status(&status[tile], kStValid | (uint64_t)total);
+    auto wait_word = [&](const uint64_t *p, uint64_t w) -> uint64_t {
+      uint32_t spins = 0;
+      while (!(w & kStValid) && spins < kSpinCap) {  // bounded: a wrong prefix beats a hung GPU
+        __builtin_amdgcn_s_sleep(1);
+        w = ld_status(p);
+        ++spins;
+      }
+      if (!(w & kStValid)) atomicAdd(reinterpret_cast<unsigned long long *>(ws + kWsTimeouts), 1ull);
+      return w & ~kStValid;
+    };
+    auto wave_total = [&](uint64_t x) -> uint64_t {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) x += __shfl_xor((unsigned long long)x, d, kWave);
+      return x;
+    };
+    // Launches of up to kFlatTiles tiles (1 M queries) sweep the tile words directly, one level: measured 3 us
+    // faster there than two levels, whose second level is one more dependent round trip. Larger launches go
+    // through the groups: the earlier tiles of this tile's group (one word per lane), then all earlier groups.
+    const bool flat = gridDim.x <= kFlatTiles;
+    const uint32_t g = tile >> 6, r = tile & 63u;
+    uint64_t in_group = 0;
+    if (!flat) {
+      const uint64_t *mine = &status[(g << 6) + (uint32_t)lane];
+      in_group = wave_total((uint32_t)lane < r ? wait_word(mine, ld_status(mine)) : 0ull);
+      if (r == 63u && lane == 0) st_status(&group[g], kStValid | (in_group + total));
+    }
+    const uint64_t *words = flat ? status : group;
+    const uint32_t nwords = flat ? tile : g;
+    uint64_t sum = 0;
+    for (uint32_t t0 = 0; t0 < nwords; t0 += 4 * kWave) {
+      uint64_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t t = t0 + j * kWave + lane;
+        w[j] = t < nwords ? ld_status(&words[t]) : kStValid;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t t = t0 + j * kWave + lane;
+        sum += t < nwords ? wait_word(&words[t], w[j]) : 0ull;
+      }
+    }
+    sum = wave_total(sum) + in_group;
+    if (lane == 0) s_base = sum + (q_begin ? offsets[q_begin] : 0ull);
+    BIVX_STAMP(4);
+  }
+  __syncthreads();
+  BIVX_STAMP(5);
+
+  // phase 2: offsets and hit ids.
+  // A query whose window was recorded replays its hit mask: the ids of its first hits wait in LDS, later ones
+  // are re-read next to their records. When every lane of a wavefront replays (the common case), the ids are
+  // first laid out in LDS exactly as they will sit in the output — the 64 lists are adjacent there — and then
+  // streamed out with coalesced stores, kStage ids per round, instead of 64 lanes each storing 4 bytes at a time
+  // into 64 different lines. Other wavefronts (several segments, long windows) enumerate again, directly.
+  uint64_t pos = s_base + local;
+#pragma unroll
+  for (int r = 0; r < kFR; ++r) {
+    const size_t q = q0 + r;
+    if (q < q_end) {
+      offsets[q] = pos;
+      if (U) counts[q] = cnt[r];
+      else if (q == q_end - 1) offsets[q_end] = pos + cnt[r];
+    }
+    const uint32_t *kept = reinterpret_cast<const uint32_t *>(&s_keep[r][threadIdx.x]);
+    // The replay cursor walks the lane's recorded windows in segment order: `mrem` holds the bits of the current
+    // window that are not consumed yet. replay(k0, k1, put) hands the ids of hits k0 .. k1-1 (consecutive calls
+    // continue where the last one stopped) to put(k, id). kGather ids are fetched per step with all their loads in
+    // flight together: one load per hit in a while-loop made every lane wait a full memory latency per id, which
+    // was most of phase 2 when queries have ~16 hits.
+    uint64_t mrem = rp[r].mask;
+    uint32_t cur_al = rp[r].al, cur_rec = 1;
+    bool cur_packed = rp[r].packed;
+    const uint32_t *xrec = reinterpret_cast<const uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]);
+    auto replay = [&](uint32_t k0, uint32_t k1, auto put) {
+      for (uint32_t k = k0; k < k1; k += kGather) {
+        uint32_t slot[kGather], ids[kGather], pk = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; ++i) {
+          slot[i] = 0;
+          if (k + i < k1) {
+            if (MS) {
+              while (mrem == 0 && cur_rec < kMaxRec) {  // next recorded window (there is one: k < the hit count)
+                const uint32_t *w = cur_rec == 1 ? kept : xrec;
+                cur_al = w[0] & ~1u;
+                cur_packed = (w[0] & 1u) != 0;
+                mrem = (uint64_t)w[1] | (uint64_t)w[2] << 32;
+                ++cur_rec;
+              }
+            }
+            slot[i] = (uint32_t)__ffsll((long long)mrem) - 1u;
+            if (MS) {
+              slot[i] += cur_al;
+              pk |= (cur_packed ? 1u : 0u) << i;
+            }
+            mrem &= mrem - 1;
+          }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; ++i) {
+          if (k + i < k1) {
+            if (rp[r].kept && k + i < kKeep) ids[i] = kept[k + i];
+            else if (MS) ids[i] = (pk >> i & 1u) ? v.rec[slot[i]].y : v.id[slot[i]];
+            else ids[i] = rp[r].packed ? v.rec[rp[r].al + slot[i]].y : v.id[rp[r].al + slot[i]];
+          }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; ++i)
+          if (k + i < k1) put(k + i, ids[i]);
+      }
+    };
+    const bool all_replay = __all(rp[r].ok);
+    const uint64_t wpos0 = __shfl((unsigned long long)pos, 0, kWave);
+    const uint32_t loff = (uint32_t)(pos - wpos0);
+    const uint32_t wtotal = __shfl(loff + cnt[r], kWave - 1, kWave);
+    if (cap == 0) {
+      // a pure count (bivx_count_dev): the offsets are all that is asked for
+    } else if (S && all_replay) {
+      // Rounds of consecutive lanes whose lists fit half the stage together (a list has at most kLight ids): ids
+      // go to one half in slot order, every lane rank-sorts its own list into the other half, and that half is
+      // streamed out coalesced.
+      uint32_t *in = s_out[wave], *outb = s_out[wave] + kStage / 2;
+      uint32_t first = 0;
+      while (first < (uint32_t)kWave) {
+        const uint32_t base = __shfl(loff, (int)first, kWave);
+        const uint64_t fit = __ballot((uint32_t)lane >= first && loff + cnt[r] - base <= kStage / 2);
+        const uint64_t nofit = ~fit & (~0ull << first);
+        const uint32_t next = nofit ? (uint32_t)__ffsll((long long)nofit) - 1u : (uint32_t)kWave;
+        const bool mine = (uint32_t)lane >= first && (uint32_t)lane < next && cnt[r] != 0;
+        const uint32_t rel = loff - base;
+        if (mine) replay(0u, cnt[r], [&](uint32_t k, uint32_t id) { in[rel + k] = id; });
+        wave_sync_mem();
+        if (mine) rank_sort_list<kFusedRankBlock>(in, outb, rel, cnt[r]);
+        wave_sync_mem();
+        const uint32_t nthis = __shfl(loff + cnt[r], (int)next - 1, kWave) - base;
+        for (uint32_t i = lane; i < nthis; i += kWave) {
+          const uint64_t p = wpos0 + base + i;
+          if (p < cap) hits[p] = outb[i];
+        }
+        wave_sync_mem();
+        first = next;
+      }
+    } else if (all_replay && wtotal >= kStageMin) {
+      uint32_t *buf = s_out[wave];
+      uint32_t kdone = 0;  // a lane's hits enter the stage in order, over one or more consecutive rounds
+      for (uint32_t base = 0; base < wtotal; base += kStage) {
+        if (kdone < cnt[r] && loff < base + kStage) {
+          const uint32_t room = base + kStage - loff;
+          const uint32_t kend = cnt[r] < room ? cnt[r] : room;
+          replay(kdone, kend, [&](uint32_t k, uint32_t id) { buf[loff + k - base] = id; });
+          kdone = kend;
+        }
+        wave_sync_mem();
+        const uint32_t nthis = wtotal - base < kStage ? wtotal - base : kStage;
+        for (uint32_t i = lane; i < nthis; i += kWave) {
+          const uint64_t p = wpos0 + base + i;
+          if (p < cap) hits[p] = buf[i];
+        }
+        wave_sync_mem();
+      }
+    } else {
+      // few ids per lane (or a wavefront that holds general-path queries): every lane stores its own list
+      if (rp[r].ok) {
+        replay(0u, cnt[r], [&](uint32_t k, uint32_t id) {
+          if (pos + k < cap) hits[pos + k] = id;
+        });
+        qy[r].nseg = 0;
+      }
+      if (!all_replay)
+        (void)enumerate_hits<Mode::Fill, F, false, MS ? kRowsWide : kRowsLean>(v, segs, qy[r], hits, pos, cap, nullptr);
+      if (S) {  // a wavefront with general-path queries: sort what it has just written (lists cut by `cap` stay cut)
+        wave_sync_mem();
+        const uint64_t e = pos + cnt[r];
+        wave_sort_lists<kStage, kFusedRankBlock>(s_out[wave], pos < cap ? pos : cap, e < cap ? e : cap, hits, lane);
+      }
+    }
+    pos += cnt[r];
+  }
+  // self-cleaning workspace: every tile bumps `done` when it leaves (its sweep is long over); the tile that
+  // sees gridDim.x - 1 knows nobody reads the words any more and zeroes them for the next launch. Off the
+  // critical path: nothing waits for this but the end of the kernel.
+  // Unordered output finds the last tile with the same word, and sums the tiles' totals in it on the way (one
+  // atomic carries both: departures in the high bits, ids in the low kDoneShift bits), so the last tile knows the
+  // launch total without reading a word other tiles are still adding to — no fence anywhere: an agent-scope fence
+  // writes back and invalidates the XCD's whole L2 on this chip, which cost more than the prefix it replaced.
+  if (self_clean || U) {
+    if (threadIdx.x == 0) {
+      if (U) {
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(ws + kWsDone),
+                                                 (1ull << kDoneShift) | (unsigned long long)total);
+        if ((old >> kDoneShift) == gridDim.x - 1) {
+          s_last = 1;
+          s_launch_total = (old & ((1ull << kDoneShift) - 1)) + total;  // ids reserved by this launch
+        }
+      } else if (atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1) {
+        s_last = 1;
+      }
+    }
+    __syncthreads();
+    if (s_last) {
+      if (!U)
+        for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) {
+          status[t] = 0;
+          if (t < (gridDim.x + kWave - 1) / kWave) group[t] = 0;
+        }
+      if (threadIdx.x == 0) {
+        if (U) {  // running total over the call's launches; the reservation counter restarts after the last one
+          const uint64_t sum = ws[kWsCarry] + s_launch_total;
+          *total_out = sum;
+          ws[kWsCarry] = (flags & kFlagFinal) ? 0 : sum;
+        }
+        if (!U || (flags & kFlagFinal)) ws[kWsTicket] = 0;
+        ws[kWsDone] = 0;
+      }
+    }
+  }
+  BIVX_STAMP(6);
+#ifdef BIVX_STAMPS
+  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kStampTiles) * 8 + 7] = tile;
+#endif
+}
+
+}  // namespace
+
+size_t fused_workspace_bytes(size_t q) {
+  (void)q;
+  return ((size_t)kFMaxTiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t);
+}
+
+size_t fused_workspace_timeouts_offset() { return (size_t)kWsTimeouts * sizeof(uint64_t); }
+
+int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
+                       const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
+                       void *d_ws, bool self_clean, bool sort_ids, hipStream_t s, uint32_t *d_counts,
+                       uint64_t *d_total) {
+  const bool unordered = d_counts != nullptr;  // begin/count output, see k_query_fused
+  if (q == 0) {
+    BIVX_HIP(hipMemsetAsync(unordered ? d_total : d_offsets, 0, sizeof(uint64_t), s));
+    return 0;
+  }
+  uint64_t *ws = static_cast<uint64_t *>(d_ws);
+  // ordered output: a launch is limited to the tiles one prefix sweep covers; unordered output has no such limit
+  // (only the departure count's 20 bits in ws[kWsDone])
+  const size_t per_launch = (size_t)(unordered ? (1u << 19) : kFMaxTiles) * kFTile;
+  // caller's workspace: zeroed in front of every launch (ordered output), or once per call (unordered output:
+  // the running total lives in it across the call's launches)
+  if (!self_clean && unordered) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));
+  for (size_t q0 = 0; q0 < q; q0 += per_launch) {
+    const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
+    const unsigned tiles = (unsigned)((q1 - q0 + kFTile - 1) / kFTile);
+    if (!self_clean && !unordered)
+      BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
+    const dim3 grid(tiles), block(kFThreads);
+    const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
+    const int flags = (self_clean ? kFlagSelfClean : 0) | (q1 == q ? kFlagFinal : 0);
+    // Ordering ids inside the kernel pays while a wavefront's 64 lists fit half its output stage (one round, all
+    // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
+    // ordered by k_sort_hits afterwards, whose stage is eight times larger.
+    const bool sort_inside = sort_ids && !unordered && cap <= (uint64_t)kFusedSortMaxAvg * q;
+#define BIVX_LAUNCH_FUSED_V(L, FL, SO, MSV, UV)                                                               \
+  hipLaunchKernelGGL((k_query_fused<L, FL, SO, MSV, UV>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, \
+                     q1, d_offsets, d_hits, cap, ws, flags, d_counts, d_total)
+#define BIVX_LAUNCH_FUSED(L, FL, SO)                       \
+  if (unordered) {                                         \
+    if (v.max_segs > 1)                                    \
+      BIVX_LAUNCH_FUSED_V(L, FL, false, true, true);       \
+    else                                                   \
+      BIVX_LAUNCH_FUSED_V(L, FL, false, false, true);      \
+  } else if (v.max_segs > 1) {                             \
+    BIVX_LAUNCH_FUSED_V(L, FL, SO, true, false);           \
+  } else {                                                 \
+    BIVX_LAUNCH_FUSED_V(L, FL, SO, false, false);          \
+  }
+    switch ((lds ? 4 : 0) | (flt ? 2 : 0) | (sort_inside ? 1 : 0)) {
+      case 0: BIVX_LAUNCH_FUSED(false, false, false); break;
+      case 1: BIVX_LAUNCH_FUSED(false, false, true); break;
+      case 2: BIVX_LAUNCH_FUSED(false, true, false); break;
+      case 3: BIVX_LAUNCH_FUSED(false, true, true); break;
+      case 4: BIVX_LAUNCH_FUSED(true, false, false); break;
+      case 5: BIVX_LAUNCH_FUSED(true, false, true); break;
+      case 6: BIVX_LAUNCH_FUSED(true, true, false); break;
+      default: BIVX_LAUNCH_FUSED(true, true, true); break;
+    }
+#undef BIVX_LAUNCH_FUSED
+#undef BIVX_LAUNCH_FUSED_V
+    if (sort_ids && !sort_inside && !unordered) {
+      BIVX_HIP(hipGetLastError());
+      if (int rc = launch_sort_hits(d_offsets + q0, d_hits, q1 - q0, cap, s)) return rc;
+    }
+  }
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+#ifdef BIVX_STAMPS
+extern "C" int bivx_debug_stamps(unsigned long long *out, size_t n) {
+  if (n > (size_t)kStampTiles * 8) n = (size_t)kStampTiles * 8;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+}  // namespace bivx
