@@ -11,14 +11,14 @@ namespace {
 // ---- single-pass kernel ----------------------------------------------------------------------------------
 // A workgroup owns kFTile = 1024 consecutive queries. It counts them (remembering each short window's hit
 // mask and the ids of its first hits), publishes its hit total, sums the totals of ALL earlier tiles, then
-// writes offsets and hit ids. The prefix is a two-level sweep, not a serial look-back chain: on MI355X every
-// poll of another XCD's status word goes to memory (per-XCD L2s are not coherent), so the number of dependent
-// polls, not their width, is what costs. Tiles form groups of 64. A tile reads the words of the earlier tiles of
-// its group (one load per lane) and the words of all earlier GROUPS (one load per lane up to 64 groups, i.e.
-// 4 M queries; four in flight beyond); the 64th tile of a group publishes the group's total as soon as it has
-// its in-group sum. So a tile waits for at most two levels, and one launch covers up to kFMaxTiles tiles (64 M
-// queries). Larger batches run as consecutive launches; each starts from the running total its predecessor left
-// in offsets[q_begin].
+// writes offsets and hit ids. The prefix is a wide sweep, not a serial look-back chain: on MI355X every poll of
+// another XCD's status word goes to memory (per-XCD L2s are not coherent), so the number of dependent polls, not
+// their width, is what costs. Launches of up to kFlatTiles tiles (1 M queries) sweep the tile words directly
+// (four loads in flight per lane). Larger launches use two levels: tiles form groups of 64, a tile reads the
+// words of the earlier tiles of its group (one load per lane) and the words of all earlier GROUPS, and the 64th
+// tile of a group publishes the group's total as soon as it has its in-group sum. One launch covers up to
+// kFMaxTiles tiles (64 M queries); larger batches run as consecutive launches, each starting from the running
+// total its predecessor left in offsets[q_begin].
 //   ws[kWsTicket] (low 32 bits): tile ticket. ws[kWsDone]: tiles that have left. ws[kWsStatus + g]: kStValid |
 //   hits of group g; ws[kWsStatus + kFMaxGroups + t]: kStValid | hits of tile t. Each is written and polled as ONE
 //   8-byte agent-scope atomic, so the value needs no separate fence. Tiles take tickets in launch order: every
@@ -39,6 +39,7 @@ constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per roun
 #define BIVX_GATHER 8
 #endif
 constexpr uint32_t kGather = BIVX_GATHER;  // ids a lane fetches per step when it replays a window in phase 2
+static_assert(kMaxRec * kLight <= kStage / 2, "a replayed list must fit half the output stage");
 constexpr uint32_t kStageMin = 320;  // ... when it has at least this many (5 per lane); below that lanes store directly
 constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
     if (cap == 0) {
       // a pure count (bivx_count_dev): the offsets are all that is asked for
     } else if (S && all_replay) {
-      // Rounds of consecutive lanes whose lists fit half the stage together (a list has at most kLight ids): ids
-      // go to one half in slot order, every lane rank-sorts its own list into the other half, and that half is
+      // Rounds of consecutive lanes whose lists fit half the stage together (a replayed list has at most
+      // kMaxRec * kLight ids, which fits by itself): ids go to one half in slot order, every lane rank-sorts its own list into the other half, and that half is
       // streamed out coalesced.
       uint32_t *in = s_out[wave], *outb = s_out[wave] + kStage / 2;
       uint32_t first = 0;
