@@ -581,3 +581,68 @@ def test_unordered_single_pass_same_sets(IntervalIndex, nq):
         assert np.array_equal(off.cpu().numpy().astype(np.uint64), ref_off)
         assert np.array_equal(hits.cpu().numpy().view(np.uint32)[:H], ref_hits)
         assert idx.stats()["prefix_timeouts"] == 0
+
+
+def test_thousands_of_chromosomes_descriptors_from_global_memory(IntervalIndex):
+    """A reference header with alternate contigs has > 3 000 chromosomes (hg38 with alts: 3 366): more chromosomes
+    and segments than the kernels stage in LDS, so they read the descriptors from global memory. Every entry
+    point against the predicate evaluated per chromosome."""
+    import torch
+    rng = np.random.default_rng(3366)
+    nchrom, n, q = 3366, 120_000, 60_000
+    chrom = rng.integers(0, nchrom, size=n).astype(np.uint32)
+    low = rng.integers(0, 3_000_000, size=n).astype(np.uint32)
+    high = low + rng.integers(0, 2_000, size=n).astype(np.uint32)
+    big = rng.choice(n, size=400, replace=False)                      # long intervals: extra length classes
+    high[big] = low[big] + rng.integers(200_000, 2_000_000, size=400).astype(np.uint32)
+    qchrom = rng.integers(0, nchrom + 50, size=q).astype(np.uint32)   # some ids beyond the index
+    qlo = rng.integers(0, 3_000_000, size=q).astype(np.uint32)
+    qhi = qlo + rng.integers(0, 3_000, size=q).astype(np.uint32)
+    # expected lists, chromosome by chromosome
+    exp = [np.zeros(0, np.int64)] * q
+    iord, qord = np.argsort(chrom, kind="stable"), np.argsort(qchrom, kind="stable")
+    ib = np.searchsorted(chrom[iord], np.arange(nchrom + 51))
+    qb = np.searchsorted(qchrom[qord], np.arange(nchrom + 51))
+    L64, H64 = low.astype(np.int64), high.astype(np.int64)
+    for c in range(nchrom):
+        ii, qi = iord[ib[c]:ib[c + 1]], qord[qb[c]:qb[c + 1]]
+        if ii.size == 0 or qi.size == 0:
+            continue
+        hit = (qlo[qi].astype(np.int64)[:, None] <= H64[ii][None, :]) & (L64[ii][None, :] <= qhi[qi].astype(np.int64)[:, None])
+        for k, qq in enumerate(qi):
+            exp[qq] = np.sort(ii[hit[k]])
+    exp_cnt = np.array([e.size for e in exp], dtype=np.int64)
+    exp_off = np.concatenate([[0], np.cumsum(exp_cnt)]).astype(np.uint64)
+    exp_hits = np.concatenate(exp).astype(np.uint32)
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high, chrom)
+        idx.build()
+        st = idx.stats()
+        assert st["n_chroms"] == nchrom and st["n_segments"] > 128
+        off, hits = idx.find_overlaps(qlo, qhi, qchrom, sort_by_id=True)           # count + fill + sort
+        assert np.array_equal(off, exp_off) and np.array_equal(hits, exp_hits)
+        first = idx.find_overlap(qlo, qhi, qchrom)
+        assert np.array_equal(first, np.array([e[0] if e.size else M32 for e in exp], dtype=np.uint32))
+        H = int(exp_off[-1])
+        d_off = torch.empty(q + 1, dtype=torch.int64, device=dev)
+        d_hits = torch.empty(H, dtype=torch.int32, device=dev)
+        for sort in (True, False):
+            idx.query_device(to(qlo), to(qhi), d_off, d_hits, qchrom=to(qchrom), sort_by_id=sort)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), exp_off)
+            got = d_hits.cpu().numpy().view(np.uint32)
+            if sort:
+                assert np.array_equal(got, exp_hits)
+            else:
+                seg = np.repeat(np.arange(q), exp_cnt)
+                assert np.array_equal(got[np.lexsort((got, seg))], exp_hits)
+        beg = torch.empty(q, dtype=torch.int64, device=dev)
+        cnt = torch.empty(q, dtype=torch.int32, device=dev)
+        tot = torch.zeros(1, dtype=torch.int64, device=dev)
+        idx.query_device_unordered(to(qlo), to(qhi), beg, cnt, d_hits, tot, qchrom=to(qchrom))
+        torch.cuda.synchronize()
+        _check_unordered(beg.cpu().numpy(), cnt.cpu().numpy(), d_hits.cpu().numpy().view(np.uint32), int(tot.item()),
+                         exp_off, exp_hits, H)
+        assert idx.stats()["prefix_timeouts"] == 0
