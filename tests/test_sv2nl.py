@@ -129,6 +129,8 @@ def test_device_filters_equal_host_predicates_on_random_data():
     n, q, d = 40000, 30000, 3000
     low = rng.integers(0, 2_000_000, n).astype(np.uint32)
     high = low + rng.integers(0, 6000, n).astype(np.uint32)
+    longer = rng.random(n) < 0.03                                # a few long SVs: several length classes per index
+    high[longer] = low[longer] + rng.integers(100_000, 900_000, int(longer.sum())).astype(np.uint32)
     inv = rng.random(n) < 0.1                                    # TRA trees hold low > high records too
     qlo = rng.integers(0, 2_000_000, q).astype(np.uint32)
     qhi = qlo + rng.integers(0, 6000, q).astype(np.uint32)
@@ -163,6 +165,20 @@ def test_device_filters_equal_host_predicates_on_random_data():
             torch.cuda.synchronize()
             assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), off), kind
             assert np.array_equal(d_hits.cpu().numpy().view(np.uint32)[: int(off[-1])], hits), kind
+            assert idx.stats()["n_segments"] >= 2
+            # and the unordered single pass with the filter: the same sets per query
+            beg = torch.empty(q, dtype=torch.int64, device=dev)
+            cnt = torch.empty(q, dtype=torch.int32, device=dev)
+            tot = torch.zeros(1, dtype=torch.int64, device=dev)
+            idx.query_device_unordered(to(qlo), to(qhi), beg, cnt, d_hits, tot, flt=dflt)
+            torch.cuda.synchronize()
+            assert int(tot.item()) == int(off[-1]), kind
+            b, c, hu = beg.cpu().numpy(), cnt.cpu().numpy().astype(np.int64), d_hits.cpu().numpy().view(np.uint32)
+            assert np.array_equal(c, np.diff(off.astype(np.int64))), kind
+            gather = np.repeat(b - np.cumsum(c) + c, c) + np.arange(int(c.sum()))
+            got = hu[gather]
+            order = np.lexsort((got, np.repeat(np.arange(q), c)))
+            assert np.array_equal(got[order], hits), kind
         qid = np.repeat(np.arange(q), np.diff(off0.astype(np.int64)))
         a_lo, a_hi = qlo[qid].astype(np.int64), qhi[qid].astype(np.int64)
         b_lo, b_hi = lo_i[hits0].astype(np.int64), hi_i[hits0].astype(np.int64)
