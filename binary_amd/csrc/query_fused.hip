@@ -40,7 +40,10 @@ constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per roun
 #endif
 constexpr uint32_t kGather = BIVX_GATHER;  // ids a lane fetches per step when it replays a window in phase 2
 static_assert(kMaxRec * kLight <= kStage / 2, "a replayed list must fit half the output stage");
-constexpr uint32_t kStageMin = 320;  // ... when it has at least this many (5 per lane); below that lanes store directly
+#ifndef BIVX_STAGE_MIN
+#define BIVX_STAGE_MIN 128
+#endif
+constexpr uint32_t kStageMin = BIVX_STAGE_MIN;  // ... when it has at least this many (2 per lane); below that lanes store directly
 constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
 // on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
