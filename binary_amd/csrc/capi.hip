@@ -3,11 +3,13 @@
 // Host code is plain C++ over the HIP runtime: it owns device memory, sequences kernels on a stream and
 // makes the one data-dependent decision of the build (length classes per chromosome). No CPU fallback:
 // every entry point needs a working gfx950 device.
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <unordered_map>
@@ -52,6 +54,11 @@ struct bivx_index {
   // stream are ordered, so they can share it); zeroed once, and every launch leaves its workspace zeroed again
   mutable std::mutex ws_mutex;
   mutable std::unordered_map<hipStream_t, void *> ws_of_stream;
+  // device blocks the host-pointer entry points used for their temporaries and handed back: a call with a handful
+  // of queries otherwise spends more time in hipMalloc / hipFree (which synchronises the device) than on the GPU
+  mutable std::mutex cache_mutex;
+  mutable std::multimap<size_t, void *> cache_free;  // block size -> block
+  mutable size_t cache_bytes = 0;
 };
 
 namespace {
@@ -82,25 +89,63 @@ struct DeviceGuard {
     return BIVX_E_HIP;                                                \
   }
 
-// frees everything allocated through it when it goes out of scope (build temporaries)
+// Temporaries of one call: everything allocated through it is handed back when it goes out of scope — to the
+// index's block cache when the block is small (the caller has synchronised its stream by then), else to hipFree.
 struct TempPool {
-  std::vector<void *> ptrs;
+  static constexpr size_t kMaxCachedBlock = 16u << 20, kMaxCachedTotal = 256u << 20;
+  const bivx_index *idx;
+  std::vector<std::pair<void *, size_t>> ptrs;
+  explicit TempPool(const bivx_index *owner) : idx(owner) {}
+  TempPool(const TempPool &) = delete;
+  TempPool &operator=(const TempPool &) = delete;
   ~TempPool() {
-    for (void *p : ptrs) (void)hipFree(p);
+    // every user has synchronised idx->stream on its way out; an error return may not have, and a recycled block
+    // must not be in use: an idle stream makes this a no-op
+    if (idx && idx->stream && !ptrs.empty()) (void)hipStreamSynchronize(idx->stream);
+    for (auto &b : ptrs) {
+      if (!b.first) continue;
+      if (idx && b.second <= kMaxCachedBlock) {
+        std::lock_guard<std::mutex> lock(idx->cache_mutex);
+        if (idx->cache_bytes + b.second <= kMaxCachedTotal) {
+          idx->cache_free.emplace(b.second, b.first);
+          idx->cache_bytes += b.second;
+          continue;
+        }
+      }
+      (void)hipFree(b.first);
+    }
   }
   template <typename T>
   int alloc(T **out, size_t count) {
+    size_t bytes = 256;  // size classes: powers of two
+    while (bytes < (count ? count : 1) * sizeof(T)) bytes <<= 1;
     void *p = nullptr;
-    BIVX_HIP(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
-    ptrs.push_back(p);
+    if (idx && bytes <= kMaxCachedBlock) {
+      std::lock_guard<std::mutex> lock(idx->cache_mutex);
+      auto it = idx->cache_free.find(bytes);
+      if (it != idx->cache_free.end()) {
+        p = it->second;
+        idx->cache_free.erase(it);
+        idx->cache_bytes -= bytes;
+      }
+    }
+    if (!p) BIVX_HIP(hipMalloc(&p, bytes));
+    ptrs.emplace_back(p, bytes);
     *out = static_cast<T *>(p);
     return 0;
   }
   void release(void *p) {  // ownership moves to the index
     for (auto &q : ptrs)
-      if (q == p) q = nullptr;
+      if (q.first == p) q.first = nullptr;
   }
 };
+
+void drop_block_cache(const bivx_index *idx) {
+  std::lock_guard<std::mutex> lock(idx->cache_mutex);
+  for (auto &kv : idx->cache_free) (void)hipFree(kv.second);
+  idx->cache_free.clear();
+  idx->cache_bytes = 0;
+}
 
 void free_built(bivx_index *idx) {
   (void)hipFree(idx->d_se);
@@ -375,6 +420,7 @@ void bivx_destroy(bivx_index *idx) {
   if (idx->stream) (void)hipStreamSynchronize(idx->stream);
   (void)hipDeviceSynchronize();
   for (auto &kv : idx->ws_of_stream) (void)hipFree(kv.second);
+  drop_block_cache(idx);
   free_built(idx);
   (void)hipFree(idx->d_chrom);
   (void)hipFree(idx->d_low);
@@ -425,7 +471,7 @@ int bivx_build(bivx_index *idx) {
   }
   free_built(idx);
   const size_t n = idx->n;
-  TempPool tmp;
+  TempPool tmp(idx);
 
   // 1. number of chromosome ids
   uint32_t *d_scalar = nullptr;
@@ -528,7 +574,7 @@ int bivx_get_intervals(const bivx_index *idx, const uint32_t *ids, size_t n, uin
   if (n == 0) return 0;
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
-  TempPool tmp;
+  TempPool tmp(idx);
   uint32_t *d_ids = nullptr, *d_c = nullptr, *d_l = nullptr, *d_h = nullptr;
   BIVX_TRY(tmp.alloc(&d_ids, n));
   if (chrom_out) BIVX_TRY(tmp.alloc(&d_c, n));
@@ -704,6 +750,56 @@ int upload_queries(TempPool &tmp, const uint32_t *qchrom, const uint32_t *qlow, 
 }  // namespace
 
 namespace {
+// A handful of queries (what reference-style code sends: one find_overlaps per record) in ONE device round trip:
+// queries packed into one upload, one launch of the single-pass kernel into a buffer sized for kSmallBatchIds hits
+// per query on average, one download of offsets and ids. A result that does not fit reports kSmallBatchOverflow
+// and the caller takes the count-then-fill path.
+constexpr size_t kSmallBatch = 2048, kSmallBatchIds = 32;
+constexpr int kSmallBatchOverflow = 1;
+int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                        size_t q, int sort_by_id, uint64_t *offsets_out, uint32_t **hit_ids_out) {
+  hipStream_t s = idx->stream;
+  const size_t nq_words = (qchrom ? 3 : 2) * q;
+  const size_t cap = kSmallBatchIds * q + 1024;
+  const size_t off_words = 2 * (q + 1);                     // u64 offsets, as u32 words
+  TempPool tmp(idx);
+  uint32_t *d_buf = nullptr;                               // [queries | pad to 8 B | offsets | ids]
+  const size_t q_words = (nq_words + 1) & ~size_t(1);
+  BIVX_TRY(tmp.alloc(&d_buf, q_words + off_words + cap));
+  std::vector<uint32_t> h(q_words > off_words + cap ? q_words : off_words + cap);
+  std::memcpy(h.data(), qlow, q * 4);
+  std::memcpy(h.data() + q, qhigh, q * 4);
+  if (qchrom) std::memcpy(h.data() + 2 * q, qchrom, q * 4);
+  BIVX_HIP(hipMemcpyAsync(d_buf, h.data(), nq_words * 4, hipMemcpyHostToDevice, s));
+  uint64_t *d_off = reinterpret_cast<uint64_t *>(d_buf + q_words);
+  uint32_t *d_hits = d_buf + q_words + off_words;
+  BIVX_TRY(bivx_query_dev_s(idx, qchrom ? d_buf + 2 * q : nullptr, d_buf, d_buf + q, q, nullptr, sort_by_id, d_off,
+                            d_hits, cap, nullptr, 0, s));
+  // offsets and the first ids in one copy: few queries rarely have more, and then a second copy fetches all
+  const size_t have = std::min(cap, 4 * q + 128);
+  BIVX_HIP(hipMemcpyAsync(h.data(), d_off, (off_words + have) * 4, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  const uint64_t *off = reinterpret_cast<const uint64_t *>(h.data());
+  const uint64_t total = off[q];
+  if (total > cap) return kSmallBatchOverflow;
+  std::memcpy(offsets_out, off, (q + 1) * 8);
+  if (total == 0) return 0;
+  uint32_t *out = static_cast<uint32_t *>(std::malloc((size_t)total * sizeof(uint32_t)));
+  if (!out) {
+    set_error("bivx_find_overlaps: out of host memory for %llu hit ids", (unsigned long long)total);
+    return BIVX_E_NOMEM;
+  }
+  if (total <= have) {
+    std::memcpy(out, h.data() + off_words, (size_t)total * 4);
+  } else if (hipMemcpy(out, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+    std::free(out);
+    set_error("bivx_find_overlaps: device copy failed");
+    return BIVX_E_HIP;
+  }
+  *hit_ids_out = out;
+  return 0;
+}
+
 // uploads a host-side filter's aux arrays; `dev` receives the same filter with device pointers
 int upload_filter(TempPool &tmp, const bivx_index *idx, const bivx_filter *f, size_t q, hipStream_t s, bivx_filter &dev) {
   dev = bivx_filter{};
@@ -744,7 +840,7 @@ int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *
   }
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
-  TempPool tmp;
+  TempPool tmp(idx);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
   uint64_t *d_off = nullptr;
@@ -777,7 +873,7 @@ int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *q
   }
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
-  TempPool tmp;
+  TempPool tmp(idx);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
   uint64_t *d_off = nullptr;
@@ -809,7 +905,11 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
   }
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
-  TempPool tmp;
+  if (q <= kSmallBatch && (!filter || filter->kind == BIVX_FILTER_NONE)) {
+    int rc = find_overlaps_small(idx, qchrom, qlow, qhigh, q, sort_by_id, offsets_out, hit_ids_out);
+    if (rc != kSmallBatchOverflow) return rc;
+  }
+  TempPool tmp(idx);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
   bivx_filter dflt;
@@ -854,7 +954,7 @@ int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow
   }
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
-  TempPool tmp;
+  TempPool tmp(idx);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
   uint32_t *d_first = nullptr;

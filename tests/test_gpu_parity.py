@@ -646,3 +646,23 @@ def test_thousands_of_chromosomes_descriptors_from_global_memory(IntervalIndex):
         _check_unordered(beg.cpu().numpy(), cnt.cpu().numpy(), d_hits.cpu().numpy().view(np.uint32), int(tot.item()),
                          exp_off, exp_hits, H)
         assert idx.stats()["prefix_timeouts"] == 0
+
+
+@pytest.mark.parametrize("q,span", [(1, 50_000), (5, 600_000), (2048, 3_000), (2049, 3_000)])
+def test_small_batches_take_one_round_trip_or_fall_back(IntervalIndex, oracle, q, span):
+    """Up to 2048 unfiltered queries go through one upload, one single-pass launch and one download; a result
+    larger than that path's buffer (few queries, very many hits each) falls back to count-then-fill. Same answers."""
+    rng = np.random.default_rng(q)
+    low = rng.integers(0, 1_000_000, size=60_000).astype(np.uint32)
+    high = low + rng.integers(0, 1_000, size=60_000).astype(np.uint32)
+    qlo = rng.integers(0, 1_000_000 - span, size=q).astype(np.uint32)
+    qhi = qlo + np.uint32(span)
+    for sort in (True, False):
+        off_g, hits_g = gpu_csr(IntervalIndex, low, high, qlo, qhi, sort_by_id=sort)
+        off_o, hits_o = oracle_csr_sorted(oracle, low, high, qlo, qhi)
+        assert np.array_equal(off_g, off_o)
+        if sort:
+            assert np.array_equal(hits_g.astype(np.int64), hits_o)
+        else:
+            seg = np.repeat(np.arange(q), np.diff(off_o.astype(np.int64)))
+            assert np.array_equal(hits_g[np.lexsort((hits_g, seg))].astype(np.int64), hits_o)
