@@ -13,8 +13,11 @@ from collections import defaultdict
 
 acc = defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "k_query_fused" in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(f)) if "k_query_fused" in r["Kernel_Name"]]
+    # the first launch of the kernel in a bench run is the zero-capacity count that sizes the hit buffer, not a step
+    first = min((int(r["Dispatch_Id"]) for r in rows), default=None)
+    for r in rows:
+        if int(r["Dispatch_Id"]) != first:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
 rd = avg.get("TCC_EA0_RDREQ_sum", 0.0)

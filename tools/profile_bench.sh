@@ -12,9 +12,9 @@ export TMPDIR=/tmp
 cd "$R"
 B="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline"
 $B > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B --no-phases > "$OUT/stats.log" 2>&1
 python3 tools/kstats.py "$OUT/stats" > "$OUT/kernel_stats.txt"
-BP="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity"
+BP="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-phases"
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d "$OUT/pmc/a" -- $BP > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc/b" -- $BP > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc/c" -- $BP > /dev/null 2>&1
