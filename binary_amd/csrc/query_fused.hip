@@ -3,6 +3,8 @@
 // ordered inside the kernel), bivx_query_dev_u (per-query begin/count, no cross-workgroup wait) and
 // bivx_count_dev (zero-capacity buffer). Replaces a batch of IntervalTree::find_overlaps calls (reference
 // interval_tree.hpp:306-334). Device building blocks: query_device.h.
+#include <cstdlib>
+
 #include "query_device.h"
 
 namespace bivx {
@@ -403,7 +405,12 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
   uint64_t *ws = static_cast<uint64_t *>(d_ws);
   // ordered output: a launch is limited to the tiles one prefix sweep covers; unordered output has no such limit
   // (only the departure count's 20 bits in ws[kWsDone])
-  const size_t per_launch = (size_t)(unordered ? (1u << 19) : kFMaxTiles) * kFTile;
+  unsigned max_tiles = unordered ? (1u << 19) : kFMaxTiles;
+  if (const char *e = std::getenv("BIVX_MAX_TILES_PER_LAUNCH")) {  // test knob: forces the chained-launch path
+    const long v = std::atol(e);
+    if (v >= 1 && v < (long)max_tiles) max_tiles = (unsigned)v;
+  }
+  const size_t per_launch = (size_t)max_tiles * kFTile;
   // caller's workspace: zeroed in front of every launch (ordered output), or once per call (unordered output:
   // the running total lives in it across the call's launches)
   if (!self_clean && unordered) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));

@@ -666,3 +666,49 @@ def test_small_batches_take_one_round_trip_or_fall_back(IntervalIndex, oracle, q
         else:
             seg = np.repeat(np.arange(q), np.diff(off_o.astype(np.int64)))
             assert np.array_equal(hits_g[np.lexsort((hits_g, seg))].astype(np.int64), hits_o)
+
+
+@pytest.mark.parametrize("max_tiles", [3, 1100])
+def test_chained_launches_of_the_single_pass(IntervalIndex, max_tiles):
+    """One launch covers 64 M queries (ordered) or more (unordered); larger batches run as consecutive launches that
+    chain through offsets[q_begin] / the workspace's running total. BIVX_MAX_TILES_PER_LAUNCH shrinks a launch so that
+    the chain runs at test size: 3 tiles (flat sweep) and 1100 tiles (two-level sweep) per launch."""
+    import torch
+    from binary_amd import synth
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    nq = 2_500_001 if max_tiles > 1000 else 20_001
+    data = synth.gen_genome(300_000, nq, 1000)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(data["low"], data["high"], data["chrom"])
+        idx.build()
+        ql, qh, qc = to(data["qlow"]), to(data["qhigh"]), to(data["qchrom"])
+        ref_off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        idx.count_overlaps_device(ql, qh, qc, offsets=ref_off)                     # one launch
+        H = int(ref_off[-1].item())
+        ref_hits = torch.empty(H, dtype=torch.int32, device=dev)
+        idx.query_device(ql, qh, ref_off, ref_hits, qchrom=qc, sort_by_id=True)
+        torch.cuda.synchronize()
+        os.environ["BIVX_MAX_TILES_PER_LAUNCH"] = str(max_tiles)
+        try:
+            for own_ws in (False, True):
+                ws = torch.empty(idx.query_workspace_bytes(nq), dtype=torch.uint8, device=dev) if own_ws else None
+                off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+                hits = torch.empty(H, dtype=torch.int32, device=dev)
+                idx.count_overlaps_device(ql, qh, qc, offsets=off)
+                assert torch.equal(off, ref_off)
+                off.zero_()
+                idx.query_device(ql, qh, off, hits, workspace=ws, qchrom=qc, sort_by_id=True)
+                assert torch.equal(off, ref_off) and torch.equal(hits, ref_hits)
+                beg = torch.empty(nq, dtype=torch.int64, device=dev)
+                cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+                tot = torch.full((1,), -1, dtype=torch.int64, device=dev)
+                for _ in range(2):                                                  # the running total restarts per call
+                    idx.query_device_unordered(ql, qh, beg, cnt, hits, tot, workspace=ws, qchrom=qc)
+                torch.cuda.synchronize()
+                _check_unordered(beg.cpu().numpy(), cnt.cpu().numpy(), hits.cpu().numpy().view(np.uint32),
+                                 int(tot.item()), ref_off.cpu().numpy().astype(np.uint64),
+                                 ref_hits.cpu().numpy().view(np.uint32), H)
+        finally:
+            del os.environ["BIVX_MAX_TILES_PER_LAUNCH"]
+        assert idx.stats()["prefix_timeouts"] == 0
