@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_last;  // this tile finished its prefix sweep last: it zeroes the workspace for the next call
   __shared__ uint32_t s_wsum[kFWaves];
+  __shared__ uint64_t s_wsum64[kFWaves];  // the same in 64 bits, for tiles with very long hit lists
   __shared__ uint64_t s_base;
   __shared__ uint64_t s_launch_total;  // unordered output, last tile only
   __shared__ uint4 s_keep[kFR][kFThreads];  // ids of each query's first kKeep hits (thread-private slots)
@@ -145,15 +146,37 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
     if (lane >= d) incl += o;
   }
   if (lane == kWave - 1) s_wsum[wave] = incl;
-  __syncthreads();
-  uint32_t wbase = 0, total = 0;
+  // 32-bit sums are exact while every query of the tile has fewer than 2^22 hits (1024 * 2^22 = 2^32). A tile
+  // with a larger list (chromosome-wide queries on a very large index) redoes the scan in 64 bits.
+  const bool wide = __syncthreads_or(tsum >= (1u << 22)) != 0;
+  uint64_t total = 0, local = 0;
+  if (!wide) {
+    uint32_t wbase = 0, total32 = 0;
 #pragma unroll
-  for (int w = 0; w < kFWaves; ++w) {
-    const uint32_t s = s_wsum[w];
-    if (w < wave) wbase += s;
-    total += s;
+    for (int w = 0; w < kFWaves; ++w) {
+      const uint32_t s = s_wsum[w];
+      if (w < wave) wbase += s;
+      total32 += s;
+    }
+    total = total32;
+    local = wbase + incl - tsum;
+  } else {
+    uint64_t incl64 = tsum;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const uint64_t o = __shfl_up((unsigned long long)incl64, d, kWave);
+      if (lane >= d) incl64 += o;
+    }
+    if (lane == kWave - 1) s_wsum64[wave] = incl64;
+    __syncthreads();
+    uint64_t wbase = 0;
+    for (int w = 0; w < kFWaves; ++w) {
+      const uint64_t s = s_wsum64[w];
+      if (w < wave) wbase += s;
+      total += s;
+    }
+    local = wbase + incl64 - tsum;
   }
-  const uint32_t local = wbase + incl - tsum;
 
   // prefix across tiles: wave 0 publishes this tile's total and sums every earlier tile's
   if (U) {

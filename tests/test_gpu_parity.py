@@ -712,3 +712,40 @@ def test_chained_launches_of_the_single_pass(IntervalIndex, max_tiles):
         finally:
             del os.environ["BIVX_MAX_TILES_PER_LAUNCH"]
         assert idx.stats()["prefix_timeouts"] == 0
+
+
+def test_tile_totals_beyond_32_bits(IntervalIndex):
+    """1 100 chromosome-wide queries over 4.2 M nested intervals: every query has 4.2 M hits (> 2^22, the bound
+    up to which a tile's 32-bit sums are exact) and one tile of 1 024 queries 4.3 G (> 2^32). Offsets, counts and the
+    total must be exact; the hit ids (18 GB) are not materialised: zero-capacity calls."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, q = 4_200_000, 1_100
+    low = np.zeros(n, np.uint32)
+    high = np.arange(1000, 1000 + n, dtype=np.uint32)
+    qlo = np.zeros(q, np.uint32)
+    qhi = np.full(q, 1000, np.uint32)
+    qhi[7] = 0          # still everything (every interval starts at 0)
+    qlo[9] = qhi[9] = 1000 + n   # beyond every interval: nothing
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    exp = np.full(q, n, np.int64)
+    exp[9] = 0
+    exp_off = np.concatenate([[0], np.cumsum(exp)])
+    assert exp_off[1024] > 2 ** 32
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        off = idx.count_overlaps_device(to(qlo), to(qhi))
+        assert np.array_equal(off.cpu().numpy(), exp_off)
+        beg = torch.empty(q, dtype=torch.int64, device=dev)
+        cnt = torch.empty(q, dtype=torch.int32, device=dev)
+        tot = torch.zeros(1, dtype=torch.int64, device=dev)
+        none = torch.empty(0, dtype=torch.int32, device=dev)
+        idx.query_device_unordered(to(qlo), to(qhi), beg, cnt, none, tot)
+        torch.cuda.synchronize()
+        assert int(tot.item()) == int(exp_off[-1])
+        assert np.array_equal(cnt.cpu().numpy().view(np.uint32).astype(np.int64), exp)
+        b = beg.cpu().numpy()
+        o = np.argsort(b[exp > 0], kind="stable")
+        bs, cs = b[exp > 0][o], exp[exp > 0][o]
+        assert bs[0] == 0 and np.array_equal(bs[1:], (bs + cs)[:-1])
