@@ -138,9 +138,9 @@ __device__ __forceinline__ uint64_t light_mask_pairs(const IndexView &v, uint32_
 // interval's low 16 coordinate bits and its length, and its append-order id right beside it, so the cache line
 // that answers "is it a hit" also says which interval it is. A window whose cells cover at most 65536
 // coordinates decodes low uniquely: low = cell0_low + ((record - cell0_low) & 0xFFFF).
-// bit j <-> slot al + j, al = a rounded down to 2. If `keep` is given, the ids of the first kKeep hits are
+// bit j <-> slot al + j, al = a rounded down to 2. If `keep` is given, the ids of the first KEEP hits are
 // written there (ascending slot order) as they are found.
-constexpr uint32_t kKeep = 4;
+constexpr uint32_t kKeep = 4;  // default number of kept ids (one uint4 slot per lane)
 
 // one chunk = 8 consecutive slots starting at the even slot c = al + c0, as four 16-byte loads
 __device__ __forceinline__ void packed_load_chunk(const IndexView &v, uint32_t c, uint32_t b, uint4 (&r)[4]) {
@@ -153,7 +153,7 @@ __device__ __forceinline__ void packed_load_chunk(const IndexView &v, uint32_t c
 }
 
 // evaluates the predicate on a loaded chunk; returns the chunk's 8-bit hit mask (bit k <-> slot c + k)
-template <bool F>
+template <bool F, uint32_t KEEP>
 __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const Window &w, uint32_t lo,
                                                       uint32_t hi, uint32_t qaux, uint32_t c, const uint4 (&r)[4],
                                                       uint32_t *keep, uint32_t &n) {
@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const 
             (!F || filter_accept(v, lo, hi, qaux, low, high, ii[e]))) {
           m |= 1u << (2 * j + e);
           if (keep) {
-            if (n < kKeep) keep[n] = ii[e];
+            if (n < KEEP) keep[n] = ii[e];
             ++n;
           }
         }
@@ -183,7 +183,7 @@ __device__ __forceinline__ uint32_t packed_eval_chunk(const IndexView &v, const 
   return m;
 }
 
-template <bool F>
+template <bool F, uint32_t KEEP = kKeep>
 __device__ __forceinline__ uint64_t light_mask_packed(const IndexView &v, const Window &w, uint32_t lo,
                                                       uint32_t hi, uint32_t qaux, uint32_t &al, uint32_t *keep) {
   al = w.a & ~1u;
@@ -194,7 +194,7 @@ __device__ __forceinline__ uint64_t light_mask_packed(const IndexView &v, const 
     if (al + c0 < w.b) {
       uint4 r[4];
       packed_load_chunk(v, al + c0, w.b, r);
-      mask |= (uint64_t)packed_eval_chunk<F>(v, w, lo, hi, qaux, al + c0, r, keep, n) << c0;
+      mask |= (uint64_t)packed_eval_chunk<F, KEEP>(v, w, lo, hi, qaux, al + c0, r, keep, n) << c0;
     }
   }
   return mask;
@@ -244,7 +244,7 @@ struct Replay {
   uint32_t al;    // aligned first slot of the (first recorded) window
   uint64_t mask;  // bit j set: slot al + j is a hit
   bool ok;
-  bool kept;      // ids of the first min(hits, kKeep) hits were written to the caller's `keep` slots
+  bool kept;      // ids of the first min(hits, KEEP) hits were written to the caller's `keep` slots
   bool packed;    // the window was read from packed records: ids sit in rec[].y
   uint32_t nrec;  // windows recorded (those with hits): the first one above, later ones in the lane's LDS slots
 };
@@ -257,7 +257,7 @@ constexpr uint32_t kMaxRec = 3;
 //   Count: returns the number of hits (and fills *rp).   Any: returns the smallest hit id (BIVX_NO_HIT if none).
 //   Fill:  writes hit ids to hits_base[dst_pos ..), in index order, only positions below `cap`;
 //          returns the number of hits.
-template <Mode M, bool F, bool MS = false, uint32_t kHeavyRows = kRowsWide>
+template <Mode M, bool F, bool MS = false, uint32_t kHeavyRows = kRowsWide, uint32_t KEEP = kKeep>
 __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const SegDesc *segs, const Query &qy,
                                                    uint32_t *hits_base, uint64_t dst_pos, uint64_t cap,
                                                    Replay *rp, uint32_t *keep = nullptr, uint32_t *xrec = nullptr) {
@@ -290,7 +290,7 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       uint64_t mask;
       const bool want = M == Mode::Count && packed && keep != nullptr && qy.nseg == 1;
       if (packed) {
-        mask = light_mask_packed<F>(v, w, lo, hi, qy.aux, al, want ? keep : nullptr);
+        mask = light_mask_packed<F, KEEP>(v, w, lo, hi, qy.aux, al, want ? keep : nullptr);
       } else {
         mask = light_mask_pairs<F>(v, w.a, w.b, lo, hi, qy.aux, al);
       }
