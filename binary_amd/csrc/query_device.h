@@ -16,8 +16,7 @@ constexpr uint32_t kLight = 64;      // window slots a lane reads by itself; lon
 #define BIVX_TRIM 512
 #endif
 constexpr uint32_t kTrim = BIVX_TRIM;  // wavefront windows longer than this are first trimmed by a 64-ary search
-constexpr uint32_t kRowsWide = 4;    // rows of 64 slots the wavefront-cooperative path keeps in flight ...
-constexpr uint32_t kRowsLean = 1;    // ... and in the one-segment single-pass kernel, which must stay spill-free in 64 VGPRs
+constexpr uint32_t kHeavyRows = 4;   // rows of 64 slots (and their ids) the wavefront-cooperative path keeps in flight
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
 constexpr uint32_t kLdsChroms = 511; // ... with chrom_seg (2 KiB); larger indexes read them from global
 
@@ -257,7 +256,7 @@ constexpr uint32_t kMaxRec = 3;
 //   Count: returns the number of hits (and fills *rp).   Any: returns the smallest hit id (BIVX_NO_HIT if none).
 //   Fill:  writes hit ids to hits_base[dst_pos ..), in index order, only positions below `cap`;
 //          returns the number of hits.
-template <Mode M, bool F, bool MS = false, uint32_t kHeavyRows = kRowsWide, uint32_t KEEP = kKeep>
+template <Mode M, bool F, bool MS = false, uint32_t KEEP = kKeep>
 __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const SegDesc *segs, const Query &qy,
                                                    uint32_t *hits_base, uint64_t dst_pos, uint64_t cap,
                                                    Replay *rp, uint32_t *keep = nullptr, uint32_t *xrec = nullptr) {

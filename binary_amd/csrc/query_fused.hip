@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   for (int r = 0; r < kFR; ++r) qy[r] = load_query<F>(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
 #pragma unroll
   for (int r = 0; r < kFR; ++r) {
-    cnt[r] = enumerate_hits<Mode::Count, F, MS, MS ? kRowsWide : kRowsLean, kKeepN>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
+    cnt[r] = enumerate_hits<Mode::Count, F, MS, kKeepN>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
                                              reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x * (kKeepN / 4)]),
                                              reinterpret_cast<uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]));
     tsum += cnt[r];
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
         qy[r].nseg = 0;
       }
       if (!all_replay)
-        (void)enumerate_hits<Mode::Fill, F, false, MS ? kRowsWide : kRowsLean>(v, segs, qy[r], hits, pos, cap, nullptr);
+        (void)enumerate_hits<Mode::Fill, F>(v, segs, qy[r], hits, pos, cap, nullptr);
       if (S) {  // a wavefront with general-path queries: sort what it has just written (lists cut by `cap` stay cut)
         wave_sync_mem();
         const uint64_t e = pos + cnt[r];
