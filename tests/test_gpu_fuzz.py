@@ -35,7 +35,12 @@ def make_case(seed):
     return chrom, low, high, qchrom, qlo.astype(np.uint32), qhi.astype(np.uint32), nchrom
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("BIVX_FUZZ_CASES", "12")))))
+# BIVX_FUZZ_CASES cases starting at seed BIVX_FUZZ_FIRST (defaults 12 and 0): long sessions walk new seeds
+_FIRST = int(__import__("os").environ.get("BIVX_FUZZ_FIRST", "0"))
+_CASES = int(__import__("os").environ.get("BIVX_FUZZ_CASES", "12"))
+
+
+@pytest.mark.parametrize("seed", list(range(_FIRST, _FIRST + _CASES)))
 def test_fuzz_against_tree_oracle(seed, oracle):
     import torch
     from binary_amd import IntervalIndex
