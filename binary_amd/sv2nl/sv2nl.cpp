@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <filesystem>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <string>
@@ -365,12 +366,21 @@ int main(int argc, char **argv) {
 
   const std::vector<std::string> parts{opt.output + ".dup", opt.output + ".inv", opt.output + ".tra"};
   try {
+    // the two files are read side by side, and the three mappers run side by side (-t 1 keeps everything on the
+    // calling thread); the reference spreads its per-chromosome tasks over a pool of -t threads (mapper.hpp:238-246)
+    const bool threaded = opt.threads != 1;
     VcfFile nl_file(opt.nl_path, "nls");
-    std::string nl_err, sv_err;
-    auto nl = nl_file.read_all(&nl_err);
-    const auto chroms = nl_file.chroms();
     VcfFile sv_file(opt.sv_path, "delly");
-    auto sv = sv_file.read_all(&sv_err);
+    std::string nl_err, sv_err;
+    std::vector<Record> nl, sv;
+    {
+      auto read_sv = [&] { sv = sv_file.read_all(&sv_err); };
+      std::future<void> f;
+      if (threaded) f = std::async(std::launch::async, read_sv);
+      nl = nl_file.read_all(&nl_err);
+      if (threaded) f.get(); else read_sv();
+    }
+    const auto chroms = nl_file.chroms();
     if (!nl_err.empty()) std::fprintf(stderr, "[sv2nl] non-linear file: %s (records after it are not mapped)\n", nl_err.c_str());
     if (!sv_err.empty()) {
       // reference: every chromosome task dies reading the SV file (exception swallowed, header-only .dup/.inv) and
@@ -379,9 +389,20 @@ int main(int argc, char **argv) {
       for (auto const &p : parts) write_part(p, {});
       return 1;
     }
-    write_part(parts[0], Mapper(Kind::Dup, "TDUP", "DUP", opt).map(sv, nl, chroms));  // main.cpp:52-58
-    write_part(parts[1], Mapper(Kind::Inv, "INV", "INV", opt).map(sv, nl, chroms));   // main.cpp:60-67
-    write_part(parts[2], Mapper(Kind::Tra, "TRA", "BND", opt).map(sv, nl, chroms));   // main.cpp:69-75
+    auto run = [&](int part, Kind kind, const char *nl_type, const char *sv_type) {
+      write_part(parts[part], Mapper(kind, nl_type, sv_type, opt).map(sv, nl, chroms));
+    };
+    if (threaded) {
+      auto dup = std::async(std::launch::async, run, 0, Kind::Dup, "TDUP", "DUP");  // main.cpp:52-58
+      auto inv = std::async(std::launch::async, run, 1, Kind::Inv, "INV", "INV");   // main.cpp:60-67
+      run(2, Kind::Tra, "TRA", "BND");                                              // main.cpp:69-75
+      dup.get();
+      inv.get();
+    } else {
+      run(0, Kind::Dup, "TDUP", "DUP");
+      run(1, Kind::Inv, "INV", "INV");
+      run(2, Kind::Tra, "TRA", "BND");
+    }
   } catch (const binary::VcfReaderError &e) {
     std::fprintf(stderr, "[sv2nl] %s\n", e.what());
     return 1;
