@@ -36,10 +36,12 @@ def test_abi_version(lib):
     assert lib.bivx_abi_version() == 0x00010003
 
 
-def test_code_object_is_gfx950(lib):
+def test_code_object_is_gfx950(lib, tmp_path):
+    import shutil
     from binary_amd._build import LIB_PATH
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", LIB_PATH],
-                         capture_output=True, text=True).stdout
+    copy = shutil.copy(LIB_PATH, tmp_path / "libbivx.so")  # --offloading drops the extracted bundles next to its input
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(copy)],
+                         capture_output=True, text=True, cwd=tmp_path).stdout
     if not out:
         pytest.skip("llvm-objdump --offloading unavailable")
     assert "gfx950" in out and "gfx9" in out
