@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restr
   }
   o0 = o0 < cap ? o0 : cap;  // a CSR that did not fit its buffer: nothing beyond the buffer is touched
   o1 = o1 < cap ? o1 : cap;
-  wave_sort_lists<kSortLds, kRankBlock>(lds[threadIdx.x >> 6], o0, o1, hits, threadIdx.x & (kWave - 1));
+  wave_sort_lists<kSortLds, kRankBlock, true>(lds[threadIdx.x >> 6], o0, o1, hits, threadIdx.x & (kWave - 1));
 }
 
 template <Mode M>

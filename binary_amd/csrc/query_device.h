@@ -16,7 +16,7 @@ constexpr uint32_t kLight = 64;      // window slots a lane reads by itself; lon
 #define BIVX_TRIM 512
 #endif
 constexpr uint32_t kTrim = BIVX_TRIM;  // wavefront windows longer than this are first trimmed by a 64-ary search
-constexpr uint32_t kHeavyRows = 4;   // rows of 64 slots (and their ids) the wavefront-cooperative path keeps in flight
+constexpr uint32_t kRows = 4;        // rows of 64 slots (and their ids) the wavefront-cooperative path keeps in flight
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
 constexpr uint32_t kLdsChroms = 511; // ... with chrom_seg (2 KiB); larger indexes read them from global
 
@@ -256,7 +256,7 @@ constexpr uint32_t kMaxRec = 3;
 //   Count: returns the number of hits (and fills *rp).   Any: returns the smallest hit id (BIVX_NO_HIT if none).
 //   Fill:  writes hit ids to hits_base[dst_pos ..), in index order, only positions below `cap`;
 //          returns the number of hits.
-template <Mode M, bool F, bool MS = false, uint32_t KEEP = kKeep>
+template <Mode M, bool F, bool MS = false, uint32_t KEEP = kKeep, uint32_t kHeavyRows = kRows>
 __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const SegDesc *segs, const Query &qy,
                                                    uint32_t *hits_base, uint64_t dst_pos, uint64_t cap,
                                                    Replay *rp, uint32_t *keep = nullptr, uint32_t *xrec = nullptr) {
@@ -506,7 +506,8 @@ __device__ __forceinline__ void rank_sort_list(const uint32_t *in, uint32_t *out
 
 // Sorts the 64 hit lists of one wavefront, hits[o0 .. o1) per lane (adjacent in memory, lane order), ascending,
 // in place. `lds` is the wavefront's own stage of LDSN words. All 64 lanes must call it.
-template <uint32_t LDSN, uint32_t RB>
+// SKIP_SORTED: look first whether every list is ascending already, and leave then.
+template <uint32_t LDSN, uint32_t RB, bool SKIP_SORTED = false>
 __device__ __forceinline__ void wave_sort_lists(uint32_t *lds, uint64_t o0, uint64_t o1, uint32_t *hits, int lane) {
   const uint64_t cnt = o1 - o0;
   // Fast path, the usual case: every list of the wavefront is short and the 64 lists fit half the stage. The
@@ -520,6 +521,14 @@ __device__ __forceinline__ void wave_sort_lists(uint32_t *lds, uint64_t o0, uint
     if (__any(cnt > 1)) {
       for (uint32_t i = lane; i < wtotal; i += kWave) in[i] = hits[wb + i];
       wave_sync_mem();
+      // Already ascending (position-sorted input has ids in index order inside a length class, so a sorted VCF
+      // mostly arrives this way): nothing to rank and nothing to write back.
+      if (SKIP_SORTED) {
+        bool ascending = true;
+        for (uint32_t i = 1; i < (uint32_t)cnt; ++i)
+          ascending = ascending && in[(uint32_t)(o0 - wb) + i - 1] < in[(uint32_t)(o0 - wb) + i];
+        if (__all(ascending)) return;
+      }
       rank_sort_list<RB>(in, outb, (uint32_t)(o0 - wb), (uint32_t)cnt);
       wave_sync_mem();
       for (uint32_t i = lane; i < wtotal; i += kWave) hits[wb + i] = outb[i];

@@ -101,6 +101,9 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   // ids of each query's first kKeepN hits (thread-private slots). Eight where LDS allows (1-2 % faster than four:
   // fewer ids are re-read in phase 2); the several-segment kernel spends that LDS on recorded windows instead.
   constexpr uint32_t kKeepN = MS ? 4 : 8;
+  // rows the wavefront-cooperative path keeps in flight: the id-ordering variants are the tightest on registers
+  // (four rows cost them 8 more bytes of scratch per lane and 4 % on configs 2-3)
+  constexpr uint32_t kRowsN = S ? 1 : kRows;
   __shared__ uint4 s_keep[kFR][kFThreads * (kKeepN / 4)];
   __shared__ uint32_t s_out[kFWaves][kStage];  // per-wavefront staging of the output ids
   __shared__ uint4 s_xrec[MS ? kFThreads : 1];  // a query's third recorded window (thread-private slots)
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   for (int r = 0; r < kFR; ++r) qy[r] = load_query<F>(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
 #pragma unroll
   for (int r = 0; r < kFR; ++r) {
-    cnt[r] = enumerate_hits<Mode::Count, F, MS, kKeepN>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
+    cnt[r] = enumerate_hits<Mode::Count, F, MS, kKeepN, kRowsN>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
                                              reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x * (kKeepN / 4)]),
                                              reinterpret_cast<uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]));
     tsum += cnt[r];
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
         qy[r].nseg = 0;
       }
       if (!all_replay)
-        (void)enumerate_hits<Mode::Fill, F>(v, segs, qy[r], hits, pos, cap, nullptr);
+        (void)enumerate_hits<Mode::Fill, F, false, kKeep, kRowsN>(v, segs, qy[r], hits, pos, cap, nullptr);
       if (S) {  // a wavefront with general-path queries: sort what it has just written (lists cut by `cap` stay cut)
         wave_sync_mem();
         const uint64_t e = pos + cnt[r];
