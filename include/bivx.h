@@ -102,7 +102,9 @@ int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlo
 
 /* One call for host callers: uploads the queries once, counts, sizes the result, enumerates (ids ascending inside each
  * query when sort_by_id != 0) and downloads. *hit_ids_out is allocated by the library (NULL when there is no hit);
- * release it with bivx_free. `filter` may be NULL. */
+ * release it with bivx_free. `filter` may be NULL. Up to 2048 unfiltered queries take one device round trip (one
+ * upload, one single-pass launch, one download), which is what a caller that keeps the reference's one
+ * find_overlaps per record pays per call. */
 int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                        size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
                        uint32_t **hit_ids_out);
@@ -110,7 +112,9 @@ void bivx_free(void *p);
 
 /* device-resident variants. bivx_count_dev is one launch of the single-pass kernel with a zero-capacity hit
  * buffer (it counts, chains the prefix across workgroups and writes d_offsets[q + 1]); since ABI 1.3 it needs no
- * caller scratch: bivx_count_workspace_bytes returns 0 and d_workspace / workspace_bytes are ignored. */
+ * caller scratch: bivx_count_workspace_bytes returns 0 and d_workspace / workspace_bytes are ignored. Like
+ * bivx_query_dev without a caller workspace it uses the index's per-stream workspace, which the first call on a
+ * stream allocates: make that call before capturing the stream into a graph. */
 size_t bivx_count_workspace_bytes(size_t q);
 int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                    const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, void *d_workspace,
