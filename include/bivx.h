@@ -198,11 +198,12 @@ int bivx_query_dev_s(const bivx_index *idx, const uint32_t *d_qchrom, const uint
 /* The single pass without the canonical CSR: for callers that only need every query's hits, not one monotone
  * offsets array (sv2nl consumes one NL record's hits at a time, mapper.hpp:205-231). A workgroup reserves the
  * output range of its 1024 queries with one atomic add and waits for nobody, so the cross-workgroup prefix —
- * about a sixth of bivx_query_dev's time at 1 M queries, more on larger batches — disappears. Query i's hits are d_hit_ids[d_begin[i] ..
- * d_begin[i] + d_count[i]) in index order; ranges of different workgroups lie in the buffer in arrival order
- * (not reproducible between calls), the sets are exactly those of bivx_query_dev. *d_total receives the number of
- * ids reserved; when it exceeds hit_capacity only slots below the capacity were written and the call is repeated
- * with a larger buffer. Workspace as for bivx_query_dev. */
+ * about a sixth of bivx_query_dev's time at 1 M queries, more on larger batches — disappears. Query i's hits
+ * are d_hit_ids[d_begin[i] .. d_begin[i] + d_count[i]) in index order; ranges of different workgroups lie in
+ * the buffer in arrival order (not reproducible between calls), the sets are exactly those of bivx_query_dev.
+ * *d_total receives the number of ids reserved; when it exceeds hit_capacity only slots below the capacity were
+ * written and the call is repeated with a larger buffer (hit_capacity 0 gives counts and the total only).
+ * Workspace as for bivx_query_dev. */
 int bivx_query_dev_u(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                      const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, uint64_t *d_begin,
                      uint32_t *d_count, uint32_t *d_hit_ids, uint64_t hit_capacity, uint64_t *d_total,
