@@ -4,7 +4,7 @@ launch of the dominant kernel (k_query_fused), per MI355X_MICROARCH.md §HBM:
   read bytes  = TCC_EA0_RDREQ split by request size (32/64/128 B); FETCH_SIZE is shown beside it — on gfx950 it
                 tallies 128-B requests at 64 B, so it reads half of the request-derived figure
   write bytes = WRITE_SIZE (KiB) cross-checked with TCC_EA0_WRREQ (64-B requests)
-usage: pmc_traffic.py <dir with the pmc passes> <out.json>"""
+usage: pmc_traffic.py <dir with the pmc passes> <out.json> [bench.json of the same command]"""
 import csv
 import glob
 import json
@@ -39,5 +39,18 @@ out = {
     "method": "read = sum over TCC_EA0_RDREQ request sizes; write = WRITE_SIZE; separate --pmc passes, "
               "averaged over the launches of the bench's timed loop",
 }
+if len(sys.argv) > 3:  # the bench line of the same command: per-query and per-algorithmic-byte ratios
+    try:
+        b = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])
+        q, alg = b["config"]["queries"], b["roofline"]["algorithmic_bytes_per_step"]
+        out["workload"] = b["config"]["workload"]
+        out["queries_per_launch"] = q
+        out["algorithmic_bytes_per_step"] = alg
+        out["traffic_over_algorithmic"] = out["traffic_bytes_per_step"] / alg
+        out["rdreq_128B_per_query"] = rd128 / q
+        out["l2_hit_rate"] = avg.get("TCC_HIT_sum", 0.0) / max(avg.get("TCC_HIT_sum", 0.0) + avg.get("TCC_MISS_sum", 0.0), 1.0)
+        out["gpu_ms_per_step_unprofiled"] = b["roofline"]["gpu_ms_per_step"]
+    except Exception as e:
+        out["bench_line_error"] = str(e)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps({k: out[k] for k in out if k != "counters_avg_per_launch"}, indent=1))
