@@ -10,15 +10,16 @@ import os
 from ._build import LIB_PATH
 
 BIVX_NO_HIT = 0xFFFFFFFF
-ABI_VERSION = 0x00010003
+E_INVALID, E_HIP, E_NOMEM, E_STATE, E_RANGE, E_TIMEOUT = -1, -2, -3, -4, -5, -6
+ABI_VERSION = 0x00020000
 
 EXPORTS = (
     "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_destroy", "bivx_device", "bivx_append",
     "bivx_append_dev", "bivx_clear", "bivx_build", "bivx_is_built", "bivx_size", "bivx_num_chroms",
-    "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_workspace_bytes", "bivx_count_dev",
+    "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
     "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f", "bivx_query_dev_s", "bivx_query_dev_u",
-    "bivx_find_overlaps", "bivx_free",
+    "bivx_find_overlaps", "bivx_free", "bivx_stream_status", "bivx_debug_corrupt_workspace",
 )
 
 
@@ -74,9 +75,9 @@ def load() -> C.CDLL:
     L.bivx_get_intervals.argtypes = [vp, u32p, sz, u32p, u32p, u32p]
     L.bivx_count.argtypes = [vp, u32p, u32p, u32p, sz, u64p]
     L.bivx_fill.argtypes = [vp, u32p, u32p, u32p, sz, u64p, u32p, C.c_int]
-    L.bivx_count_workspace_bytes.argtypes = [sz]
-    L.bivx_count_workspace_bytes.restype = sz
-    L.bivx_count_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, vp, sz, vp]
+    L.bivx_count_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, vp]
+    L.bivx_stream_status.argtypes = [vp, vp]
+    L.bivx_debug_corrupt_workspace.argtypes = [vp, vp]
     L.bivx_fill_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, u32p, vp]
     L.bivx_query_workspace_bytes.argtypes = [sz]
     L.bivx_query_workspace_bytes.restype = sz
@@ -91,7 +92,7 @@ def load() -> C.CDLL:
     L.bivx_free.restype = None
     L.bivx_count_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p]
     L.bivx_fill_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, C.c_int]
-    L.bivx_count_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, vp, sz, vp]
+    L.bivx_count_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, vp]
     L.bivx_fill_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, vp]
     L.bivx_query_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, C.c_uint64, vp, sz, vp]
     L.bivx_query_dev_s.argtypes = [vp, u32p, u32p, u32p, sz, fp, C.c_int, u64p, u32p, C.c_uint64, vp, sz, vp]

@@ -4,6 +4,7 @@
 // makes the one data-dependent decision of the build (length classes per chromosome). No CPU fallback:
 // every entry point needs a working gfx950 device.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -52,8 +53,17 @@ struct bivx_index {
   double build_ms = 0.0;
   // prefix workspaces of bivx_query_dev calls made without a caller workspace: one per stream (calls on one
   // stream are ordered, so they can share it); zeroed once, and every launch leaves its workspace zeroed again
+  struct Workspace {
+    void *p = nullptr;
+    bool needs_reset = false;  // a reported error may have left protocol state behind: cleared before the next launch
+  };
   mutable std::mutex ws_mutex;
-  mutable std::unordered_map<hipStream_t, void *> ws_of_stream;
+  mutable std::unordered_map<hipStream_t, Workspace> ws_of_stream;
+  // error block of the kernels (IndexView::err): pinned host memory mapped into the device, so that every
+  // synchronising entry point can look at it without a copy
+  uint32_t *h_err = nullptr;  // host address
+  uint32_t *d_err = nullptr;  // the same memory as the device sees it
+  mutable std::atomic<uint64_t> errors_reported{0};
   // device blocks the host-pointer entry points used for their temporaries and handed back: a call with a handful
   // of queries otherwise spends more time in hipMalloc / hipFree (which synchronises the device) than on the GPU
   mutable std::mutex cache_mutex;
@@ -175,14 +185,26 @@ int ensure_capacity(bivx_index *idx, size_t need) {
   if (nc < need) nc = need;
   if (nc > 0xFFFFFFFEull) nc = 0xFFFFFFFEull;
   uint32_t *c = nullptr, *l = nullptr, *h = nullptr;
-  BIVX_HIP(hipMalloc((void **)&c, nc * sizeof(uint32_t)));
-  BIVX_HIP(hipMalloc((void **)&l, nc * sizeof(uint32_t)));
-  BIVX_HIP(hipMalloc((void **)&h, nc * sizeof(uint32_t)));
-  if (idx->n) {
-    BIVX_HIP(hipMemcpyAsync(c, idx->d_chrom, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
-    BIVX_HIP(hipMemcpyAsync(l, idx->d_low, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
-    BIVX_HIP(hipMemcpyAsync(h, idx->d_high, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
-    BIVX_HIP(hipStreamSynchronize(idx->stream));
+  auto grow = [&]() -> int {
+    BIVX_HIP(hipMalloc((void **)&c, nc * sizeof(uint32_t)));
+    BIVX_HIP(hipMalloc((void **)&l, nc * sizeof(uint32_t)));
+    BIVX_HIP(hipMalloc((void **)&h, nc * sizeof(uint32_t)));
+    if (idx->n) {
+      // Earlier bivx_append_dev calls copy on the CALLER's streams, which idx->stream is not ordered after: wait
+      // for the whole device before the old arrays are read and freed (growth doubles, so this is rare).
+      BIVX_HIP(hipDeviceSynchronize());
+      BIVX_HIP(hipMemcpyAsync(c, idx->d_chrom, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
+      BIVX_HIP(hipMemcpyAsync(l, idx->d_low, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
+      BIVX_HIP(hipMemcpyAsync(h, idx->d_high, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
+      BIVX_HIP(hipStreamSynchronize(idx->stream));
+    }
+    return 0;
+  };
+  if (int rc = grow()) {
+    (void)hipFree(c);
+    (void)hipFree(l);
+    (void)hipFree(h);
+    return rc;
   }
   (void)hipFree(idx->d_chrom);
   (void)hipFree(idx->d_low);
@@ -337,7 +359,28 @@ IndexView view_of(const bivx_index *idx) {
   v.flt_strand = 0;
   v.flt_qaux = nullptr;
   v.flt_iaux = nullptr;
+  v.err = idx->d_err;
   return v;
+}
+
+// Turns a raised error word into BIVX_E_TIMEOUT, once. Call after a synchronisation that covers the kernels in
+// question. The words are reset and every index-owned workspace is cleared before its next launch.
+int report_device_errors(const bivx_index *idx, const char *who) {
+  volatile uint32_t *e = idx->h_err;
+  const bool timeout = e[kErrTimeout] != 0, dirty = e[kErrWorkspace] != 0;
+  if (!timeout && !dirty) return 0;
+  e[kErrTimeout] = 0;
+  e[kErrWorkspace] = 0;
+  idx->errors_reported.fetch_add(1);
+  {
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    for (auto &kv : idx->ws_of_stream) kv.second.needs_reset = true;
+  }
+  set_error("%s: %s%s%s: the result of that call is invalid, repeat it", who,
+            timeout ? "a single-pass query kernel gave up waiting for an earlier workgroup's hit total" : "",
+            timeout && dirty ? "; " : "",
+            dirty ? "a single-pass query kernel found its prefix workspace not zeroed" : "");
+  return BIVX_E_TIMEOUT;
 }
 
 // view with a fused post-filter; the aux pointers are DEVICE pointers here
@@ -410,6 +453,18 @@ int bivx_create(bivx_index **out, int device) {
     delete idx;
     return BIVX_E_HIP;
   }
+  void *herr = nullptr, *derr = nullptr;
+  if (hipHostMalloc(&herr, kErrWords * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(&derr, herr, 0) != hipSuccess) {
+    set_error("bivx_create: cannot map the error block into device %d", device);
+    if (herr) (void)hipHostFree(herr);
+    (void)hipStreamDestroy(idx->stream);
+    delete idx;
+    return BIVX_E_HIP;
+  }
+  std::memset(herr, 0, kErrWords * sizeof(uint32_t));
+  idx->h_err = static_cast<uint32_t *>(herr);
+  idx->d_err = static_cast<uint32_t *>(derr);
   *out = idx;
   return 0;
 }
@@ -419,7 +474,8 @@ void bivx_destroy(bivx_index *idx) {
   DeviceGuard g(idx->device);
   if (idx->stream) (void)hipStreamSynchronize(idx->stream);
   (void)hipDeviceSynchronize();
-  for (auto &kv : idx->ws_of_stream) (void)hipFree(kv.second);
+  for (auto &kv : idx->ws_of_stream) (void)hipFree(kv.second.p);
+  if (idx->h_err) (void)hipHostFree(idx->h_err);
   drop_block_cache(idx);
   free_built(idx);
   (void)hipFree(idx->d_chrom);
@@ -467,7 +523,7 @@ int bivx_build(bivx_index *idx) {
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     // on the build stream, which is synchronised before bivx_build returns (a plain hipMemset runs on the null
     // stream, which non-blocking streams do not wait for)
-    for (auto &kv : idx->ws_of_stream) BIVX_HIP(hipMemsetAsync(kv.second, 0, fused_workspace_bytes(0), s));
+    for (auto &kv : idx->ws_of_stream) BIVX_HIP(hipMemsetAsync(kv.second.p, 0, fused_workspace_bytes(0), s));
   }
   free_built(idx);
   const size_t n = idx->n;
@@ -589,11 +645,6 @@ int bivx_get_intervals(const bivx_index *idx, const uint32_t *ids, size_t n, uin
   return 0;
 }
 
-size_t bivx_count_workspace_bytes(size_t q) {
-  (void)q;
-  return 0;  // bivx_count_dev needs no caller scratch since ABI 1.3 (it is one launch of the single-pass kernel)
-}
-
 namespace {
 int query_single_pass(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *d_offsets, uint32_t *d_counts,
@@ -602,18 +653,15 @@ int query_single_pass(const bivx_index *idx, const uint32_t *d_qchrom, const uin
 }
 
 int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
-                   size_t q, uint64_t *d_offsets, void *d_workspace, size_t workspace_bytes, void *stream) {
-  return bivx_count_dev_f(idx, d_qchrom, d_qlow, d_qhigh, q, nullptr, d_offsets, d_workspace, workspace_bytes, stream);
+                   size_t q, uint64_t *d_offsets, void *stream) {
+  return bivx_count_dev_f(idx, d_qchrom, d_qlow, d_qhigh, q, nullptr, d_offsets, stream);
 }
 
 int bivx_count_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
-                     size_t q, const bivx_filter *filter, uint64_t *d_offsets, void *d_workspace,
-                     size_t workspace_bytes, void *stream) {
+                     size_t q, const bivx_filter *filter, uint64_t *d_offsets, void *stream) {
   // One launch of the single-pass kernel with a zero-capacity hit buffer: it counts, chains the prefix across
   // workgroups and writes the offsets, and skips the output phase. (The counts + three-launch scan it replaces
-  // took 55 us at config 2, this takes 40.) The caller's workspace is not needed any more and is ignored.
-  (void)d_workspace;
-  (void)workspace_bytes;
+  // took 55 us at config 2, this takes 40.)
   return query_single_pass(idx, d_qchrom, d_qlow, d_qhigh, q, filter, 0, d_offsets, nullptr, nullptr, 0, nullptr,
                            nullptr, 0, stream, "bivx_count_dev");
 }
@@ -675,13 +723,26 @@ int query_single_pass(const bivx_index *idx, const uint32_t *d_qchrom, const uin
   if (!d_workspace) {  // the index's own per-stream workspace: no memset in front of the kernel
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     auto it = idx->ws_of_stream.find(s);
-    if (it == idx->ws_of_stream.end()) {
-      void *p = nullptr;
-      BIVX_HIP(hipMalloc(&p, fused_workspace_bytes(q)));
-      BIVX_HIP(hipMemsetAsync(p, 0, fused_workspace_bytes(q), s));  // ordered before the kernel: same stream
-      it = idx->ws_of_stream.emplace(s, p).first;
+    if (it == idx->ws_of_stream.end() || it->second.needs_reset) {
+      // (re)initialising a workspace is a memset that must run exactly once, before the first launch: inside a
+      // stream capture it would become a node that a replay repeats (or that is never run at all)
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        set_error("%s: the first call on a stream (and the first after an error) allocates and clears the index's "
+                  "prefix workspace and cannot be captured: make one call on this stream before the capture", who);
+        return BIVX_E_STATE;
+      }
+      if (it == idx->ws_of_stream.end()) {
+        void *p = nullptr;
+        BIVX_HIP(hipMalloc(&p, fused_workspace_bytes(q)));
+        bivx_index::Workspace w;
+        w.p = p;
+        it = idx->ws_of_stream.emplace(s, w).first;
+      }
+      BIVX_HIP(hipMemsetAsync(it->second.p, 0, fused_workspace_bytes(q), s));  // ordered before the kernel: same stream
+      it->second.needs_reset = false;
     }
-    d_workspace = it->second;
+    d_workspace = it->second.p;
     self_clean = true;
   }
   return launch_query_fused(view, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, hit_capacity, d_workspace,
@@ -707,6 +768,33 @@ int bivx_query_dev_u(const bivx_index *idx, const uint32_t *d_qchrom, const uint
   uint32_t dummy = 0;
   return query_single_pass(idx, d_qchrom, d_qlow, d_qhigh, q, filter, 0, d_begin, q ? d_count : &dummy, d_hit_ids,
                            hit_capacity, d_total, d_workspace, workspace_bytes, stream, "bivx_query_dev_u");
+}
+
+int bivx_stream_status(const bivx_index *idx, void *stream) {
+  if (!idx) {
+    set_error("bivx_stream_status: null index");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  BIVX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return report_device_errors(idx, "bivx_stream_status");
+}
+
+int bivx_debug_corrupt_workspace(const bivx_index *idx, void *stream) {
+  if (!idx) {
+    set_error("bivx_debug_corrupt_workspace: null index");
+    return BIVX_E_INVALID;
+  }
+  BIVX_GUARD(idx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(idx->ws_mutex);
+  auto it = idx->ws_of_stream.find(s);
+  if (it == idx->ws_of_stream.end()) {
+    set_error("bivx_debug_corrupt_workspace: no workspace for this stream yet");
+    return BIVX_E_STATE;
+  }
+  BIVX_HIP(hipMemsetAsync(it->second.p, 0x7F, sizeof(uint32_t), s));  // ticket word: far beyond any grid
+  return 0;
 }
 
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q, void *stream) {
@@ -779,6 +867,7 @@ int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uin
   const size_t have = std::min(cap, 4 * q + 128);
   BIVX_HIP(hipMemcpyAsync(h.data(), d_off, (off_words + have) * 4, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
+  BIVX_TRY(report_device_errors(idx, "bivx_find_overlaps"));
   const uint64_t *off = reinterpret_cast<const uint64_t *>(h.data());
   const uint64_t total = off[q];
   if (total > cap) return kSmallBatchOverflow;
@@ -847,10 +936,10 @@ int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *
   BIVX_TRY(tmp.alloc(&d_off, q + 1));
   bivx_filter dflt;
   BIVX_TRY(upload_filter(tmp, idx, filter, q, s, dflt));
-  BIVX_TRY(bivx_count_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, nullptr, 0, s));
+  BIVX_TRY(bivx_count_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, s));
   BIVX_HIP(hipMemcpyAsync(offsets_out, d_off, (q + 1) * 8, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
-  return 0;
+  return report_device_errors(idx, "bivx_count");
 }
 
 int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
@@ -887,7 +976,7 @@ int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *q
   if (sort_by_id) BIVX_TRY(bivx_sort_hits_dev(idx, d_off, d_hits, q, s));
   if (total) BIVX_HIP(hipMemcpyAsync(hit_ids_out, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
-  return 0;
+  return report_device_errors(idx, "bivx_fill");
 }
 
 int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
@@ -916,11 +1005,12 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
   BIVX_TRY(upload_filter(tmp, idx, filter, q, s, dflt));
   uint64_t *d_off = nullptr;
   BIVX_TRY(tmp.alloc(&d_off, q + 1));
-  BIVX_TRY(bivx_count_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, nullptr, 0, s));
+  BIVX_TRY(bivx_count_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, s));
   uint64_t total = 0;
   BIVX_HIP(hipMemcpyAsync(&total, d_off + q, 8, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipMemcpyAsync(offsets_out, d_off, (q + 1) * 8, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
+  BIVX_TRY(report_device_errors(idx, "bivx_find_overlaps"));
   if (total == 0) return 0;
   uint32_t *h = static_cast<uint32_t *>(std::malloc((size_t)total * sizeof(uint32_t)));
   if (!h) {
@@ -980,16 +1070,9 @@ int bivx_get_stats(const bivx_index *idx, bivx_stats *out) {
     out->index_bytes = (uint64_t)idx->built_n * 20 + idx->nentries * 4 + (uint64_t)idx->nseg * sizeof(SegDesc) +
                        ((uint64_t)idx->nchrom + 1) * 4;
   out->build_ms = idx->build_ms;
-  {  // bounded prefix waits of the single-pass kernel that gave up (index-owned workspaces): expected to stay 0
-    BIVX_GUARD(idx);
-    std::lock_guard<std::mutex> lock(idx->ws_mutex);
-    for (auto &kv : idx->ws_of_stream) {
-      uint32_t t = 0;
-      BIVX_HIP(hipDeviceSynchronize());
-      BIVX_HIP(hipMemcpy(&t, static_cast<const uint8_t *>(kv.second) + fused_workspace_timeouts_offset(), 4,
-                         hipMemcpyDeviceToHost));
-      out->prefix_timeouts += t;
-    }
+  {
+    volatile uint32_t *e = idx->h_err;
+    out->prefix_timeouts = idx->errors_reported.load() + ((e[kErrTimeout] | e[kErrWorkspace]) ? 1u : 0u);
   }
   return 0;
 }

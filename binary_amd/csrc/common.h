@@ -62,7 +62,12 @@ struct IndexView {
   uint32_t flt_strand;
   const uint32_t *flt_qaux;   // per query
   const uint32_t *flt_iaux;   // per interval, append order
+  // the index's error block: host memory mapped into the device; kernels only ever store 1 into its words
+  uint32_t *err;
 };
+constexpr uint32_t kErrTimeout = 0;    // a bounded cross-workgroup wait of the single-pass kernel expired
+constexpr uint32_t kErrWorkspace = 1;  // the prefix workspace was not zero when a launch began
+constexpr uint32_t kErrWords = 16;     // size of the block (one cache line)
 
 // per (chromosome, length bin) statistics gathered before the sort
 struct BinStats {
@@ -109,7 +114,6 @@ int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_q
 int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, uint64_t cap, hipStream_t s);
 // single pass: offsets[q+1] and hits (slots below cap only) in one kernel; ws: fused_workspace_bytes(q)
 size_t fused_workspace_bytes(size_t q);
-size_t fused_workspace_timeouts_offset();  // byte offset of the "prefix wait gave up" counter inside a workspace
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
                        void *d_ws, bool self_clean, bool sort_ids, hipStream_t s, uint32_t *d_counts = nullptr,

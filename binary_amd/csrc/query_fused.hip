@@ -30,9 +30,9 @@ namespace {
 #endif
 constexpr int kFThreads = BIVX_FUSED_THREADS;
 constexpr int kFWaves = kFThreads / kWave;
-constexpr int kFR = 1;  // queries per thread. (More per thread was measured and did not pay: a wavefront here is
-                        // latency-bound, and the output staging below assumes the 64 lists of a wavefront are adjacent.)
-constexpr int kFTile = kFThreads * kFR;
+// One query per thread. (More per thread was measured and did not pay: a wavefront here is latency-bound, and the
+// output staging below relies on the 64 lists of a wavefront being adjacent.)
+constexpr int kFTile = kFThreads;
 constexpr unsigned kFMaxTiles = 65536;                 // tiles per launch (ordered output)
 constexpr unsigned kFMaxGroups = kFMaxTiles / kWave;   // groups of 64 tiles
 constexpr unsigned kFlatTiles = 1024;                  // launches up to this many tiles sweep the tile words directly
@@ -49,11 +49,19 @@ constexpr uint32_t kStageMin = BIVX_STAGE_MIN;  // ... when it has at least this
 constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
 // on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
-constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsTimeouts = 24, kWsStatus = 32;
-// (kWsTimeouts is never cleared by the kernel)
+constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsStatus = 32;
 constexpr uint32_t kDoneShift = 44;  // unordered output: ws[kWsDone] = departures << 44 | ids reserved by this launch
-constexpr uint32_t kSpinCap = 1u << 20;
-constexpr int kFlagSelfClean = 1, kFlagFinal = 2;  // k_query_fused flags: index-owned workspace; last launch of the call
+// k_query_fused flags: index-owned workspace; last launch of the call; bits 8-15: log2 of the bound on a prefix
+// wait in ticks of the 100 MHz constant clock (0 = kWaitLog2Default)
+constexpr int kFlagSelfClean = 1, kFlagFinal = 2, kFlagWaitShift = 8;
+constexpr uint32_t kWaitLog2Default = 31;  // 2^31 x 10 ns = 21 s: only a device that stopped making progress gets there
+
+// A workgroup that cannot produce a valid result says so in the index's error block (host memory mapped into the
+// device: the host reads it without a copy after any synchronisation) instead of returning quietly; every
+// synchronising entry point and bivx_stream_status turn a raised word into BIVX_E_TIMEOUT (capi.hip).
+__device__ __forceinline__ void raise_error(uint32_t *err, uint32_t which) {
+  __hip_atomic_store(err + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   // rows the wavefront-cooperative path keeps in flight: the id-ordering variants are the tightest on registers
   // (four rows cost them 8 more bytes of scratch per lane and 4 % on configs 2-3)
   constexpr uint32_t kRowsN = S ? 1 : kRows;
-  __shared__ uint4 s_keep[kFR][kFThreads * (kKeepN / 4)];
+  __shared__ uint4 s_keep[kFThreads * (kKeepN / 4)];
   __shared__ uint32_t s_out[kFWaves][kStage];  // per-wavefront staging of the output ids
   __shared__ uint4 s_xrec[MS ? kFThreads : 1];  // a query's third recorded window (thread-private slots)
   const int lane = threadIdx.x & (kWave - 1);
@@ -123,25 +131,22 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   const uint32_t tile = s_tile;
   uint64_t *group = ws + kWsStatus, *status = group + kFMaxGroups;
   BIVX_STAMP(1);
-  // A ticket beyond the grid means the workspace was not zeroed (a caller bug): leave without touching memory
-  // rather than index the status array and the queries with it.
-  if (tile >= gridDim.x) return;
-
-  // phase 1: count the thread's kFR consecutive queries
-  const size_t q0 = q_begin + ((size_t)tile * kFThreads + threadIdx.x) * kFR;
-  Query qy[kFR];
-  Replay rp[kFR];
-  uint32_t cnt[kFR];
-  uint32_t tsum = 0;
-#pragma unroll
-  for (int r = 0; r < kFR; ++r) qy[r] = load_query<F>(v, cs, qchrom, qlow, qhigh, q0 + r, q0 + r < q_end);
-#pragma unroll
-  for (int r = 0; r < kFR; ++r) {
-    cnt[r] = enumerate_hits<Mode::Count, F, MS, kKeepN, kRowsN>(v, segs, qy[r], nullptr, 0, 0, &rp[r],
-                                             reinterpret_cast<uint32_t *>(&s_keep[r][threadIdx.x * (kKeepN / 4)]),
-                                             reinterpret_cast<uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]));
-    tsum += cnt[r];
+  // A ticket beyond the grid means the workspace was not zero when the launch began (a launch that died half-way,
+  // a caller workspace that was not cleared): nothing this launch writes can be trusted. Say so and leave without
+  // indexing the status array or the queries with the ticket.
+  if (tile >= gridDim.x) {
+    if (threadIdx.x == 0) raise_error(v.err, kErrWorkspace);
+    return;
   }
+
+  // phase 1: count the thread's query
+  const size_t q = q_begin + (size_t)tile * kFThreads + threadIdx.x;
+  Query qy = load_query<F>(v, cs, qchrom, qlow, qhigh, q, q < q_end);
+  Replay rp;
+  uint32_t *const kept = reinterpret_cast<uint32_t *>(&s_keep[threadIdx.x * (kKeepN / 4)]);
+  uint32_t *const xrec = reinterpret_cast<uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]);
+  const uint32_t cnt = enumerate_hits<Mode::Count, F, MS, kKeepN, kRowsN>(v, segs, qy, nullptr, 0, 0, &rp, kept, xrec);
+  const uint32_t tsum = cnt;
 
   BIVX_STAMP(2);
   // workgroup exclusive scan of the per-thread sums
@@ -191,14 +196,22 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   } else if (wave == 0) {
     BIVX_STAMP(3);
     if (lane == 0) st_status(&status[tile], kStValid | (uint64_t)total);
+    // Bounded by wall time, not by a poll count: a predecessor whose phase 1 walks chromosome-wide windows may
+    // legitimately take seconds. When the bound expires the tile goes on with a wrong prefix — a hung GPU helps
+    // nobody — and raises the error word, which no entry point lets pass as success.
+    const uint32_t wl = ((uint32_t)flags >> kFlagWaitShift) & 0xFFu;
+    const uint64_t wait_ticks = 1ull << (wl ? wl : kWaitLog2Default);
     auto wait_word = [&](const uint64_t *p, uint64_t w) -> uint64_t {
-      uint32_t spins = 0;
-      while (!(w & kStValid) && spins < kSpinCap) {  // bounded: a wrong prefix beats a hung GPU
-        __builtin_amdgcn_s_sleep(1);
-        w = ld_status(p);
-        ++spins;
+      if (!(w & kStValid)) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        for (uint32_t spins = 1;; ++spins) {
+          __builtin_amdgcn_s_sleep(1);
+          w = ld_status(p);
+          if (w & kStValid) break;
+          if ((spins & 15u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > wait_ticks) break;
+        }
+        if (!(w & kStValid)) raise_error(v.err, kErrTimeout);
       }
-      if (!(w & kStValid)) atomicAdd(reinterpret_cast<unsigned long long *>(ws + kWsTimeouts), 1ull);
       return w & ~kStValid;
     };
     auto wave_total = [&](uint64_t x) -> uint64_t {
@@ -246,25 +259,21 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   // first laid out in LDS exactly as they will sit in the output — the 64 lists are adjacent there — and then
   // streamed out with coalesced stores, kStage ids per round, instead of 64 lanes each storing 4 bytes at a time
   // into 64 different lines. Other wavefronts (several segments, long windows) enumerate again, directly.
-  uint64_t pos = s_base + local;
-#pragma unroll
-  for (int r = 0; r < kFR; ++r) {
-    const size_t q = q0 + r;
+  const uint64_t pos = s_base + local;
+  {
     if (q < q_end) {
       offsets[q] = pos;
-      if (U) counts[q] = cnt[r];
-      else if (q == q_end - 1) offsets[q_end] = pos + cnt[r];
+      if (U) counts[q] = cnt;
+      else if (q == q_end - 1) offsets[q_end] = pos + cnt;
     }
-    const uint32_t *kept = reinterpret_cast<const uint32_t *>(&s_keep[r][threadIdx.x * (kKeepN / 4)]);
     // The replay cursor walks the lane's recorded windows in segment order: `mrem` holds the bits of the current
     // window that are not consumed yet. replay(k0, k1, put) hands the ids of hits k0 .. k1-1 (consecutive calls
     // continue where the last one stopped) to put(k, id). kGather ids are fetched per step with all their loads in
     // flight together: one load per hit in a while-loop made every lane wait a full memory latency per id, which
     // was most of phase 2 when queries have ~16 hits.
-    uint64_t mrem = rp[r].mask;
-    uint32_t cur_al = rp[r].al, cur_rec = 1;
-    bool cur_packed = rp[r].packed;
-    const uint32_t *xrec = reinterpret_cast<const uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]);
+    uint64_t mrem = rp.mask;
+    uint32_t cur_al = rp.al, cur_rec = 1;
+    bool cur_packed = rp.packed;
     auto replay = [&](uint32_t k0, uint32_t k1, auto put) {
       for (uint32_t k = k0; k < k1; k += kGather) {
         uint32_t slot[kGather], ids[kGather], pk = 0;
@@ -292,9 +301,9 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
 #pragma unroll
         for (uint32_t i = 0; i < kGather; ++i) {
           if (k + i < k1) {
-            if (rp[r].kept && k + i < kKeepN) ids[i] = kept[k + i];
+            if (rp.kept && k + i < kKeepN) ids[i] = kept[k + i];
             else if (MS) ids[i] = (pk >> i & 1u) ? v.rec[slot[i]].y : v.id[slot[i]];
-            else ids[i] = rp[r].packed ? v.rec[rp[r].al + slot[i]].y : v.id[rp[r].al + slot[i]];
+            else ids[i] = rp.packed ? v.rec[rp.al + slot[i]].y : v.id[rp.al + slot[i]];
           }
         }
 #pragma unroll
@@ -302,10 +311,10 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
           if (k + i < k1) put(k + i, ids[i]);
       }
     };
-    const bool all_replay = __all(rp[r].ok);
+    const bool all_replay = __all(rp.ok);
     const uint64_t wpos0 = __shfl((unsigned long long)pos, 0, kWave);
     const uint32_t loff = (uint32_t)(pos - wpos0);
-    const uint32_t wtotal = __shfl(loff + cnt[r], kWave - 1, kWave);
+    const uint32_t wtotal = __shfl(loff + cnt, kWave - 1, kWave);
     if (cap == 0) {
       // a pure count (bivx_count_dev): the offsets are all that is asked for
     } else if (S && all_replay) {
@@ -316,16 +325,16 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
       uint32_t first = 0;
       while (first < (uint32_t)kWave) {
         const uint32_t base = __shfl(loff, (int)first, kWave);
-        const uint64_t fit = __ballot((uint32_t)lane >= first && loff + cnt[r] - base <= kStage / 2);
+        const uint64_t fit = __ballot((uint32_t)lane >= first && loff + cnt - base <= kStage / 2);
         const uint64_t nofit = ~fit & (~0ull << first);
         const uint32_t next = nofit ? (uint32_t)__ffsll((long long)nofit) - 1u : (uint32_t)kWave;
-        const bool mine = (uint32_t)lane >= first && (uint32_t)lane < next && cnt[r] != 0;
+        const bool mine = (uint32_t)lane >= first && (uint32_t)lane < next && cnt != 0;
         const uint32_t rel = loff - base;
-        if (mine) replay(0u, cnt[r], [&](uint32_t k, uint32_t id) { in[rel + k] = id; });
+        if (mine) replay(0u, cnt, [&](uint32_t k, uint32_t id) { in[rel + k] = id; });
         wave_sync_mem();
-        if (mine) rank_sort_list<kFusedRankBlock>(in, outb, rel, cnt[r]);
+        if (mine) rank_sort_list<kFusedRankBlock>(in, outb, rel, cnt);
         wave_sync_mem();
-        const uint32_t nthis = __shfl(loff + cnt[r], (int)next - 1, kWave) - base;
+        const uint32_t nthis = __shfl(loff + cnt, (int)next - 1, kWave) - base;
         for (uint32_t i = lane; i < nthis; i += kWave) {
           const uint64_t p = wpos0 + base + i;
           if (p < cap) hits[p] = outb[i];
@@ -337,9 +346,9 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
       uint32_t *buf = s_out[wave];
       uint32_t kdone = 0;  // a lane's hits enter the stage in order, over one or more consecutive rounds
       for (uint32_t base = 0; base < wtotal; base += kStage) {
-        if (kdone < cnt[r] && loff < base + kStage) {
+        if (kdone < cnt && loff < base + kStage) {
           const uint32_t room = base + kStage - loff;
-          const uint32_t kend = cnt[r] < room ? cnt[r] : room;
+          const uint32_t kend = cnt < room ? cnt : room;
           replay(kdone, kend, [&](uint32_t k, uint32_t id) { buf[loff + k - base] = id; });
           kdone = kend;
         }
@@ -353,21 +362,20 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
       }
     } else {
       // few ids per lane (or a wavefront that holds general-path queries): every lane stores its own list
-      if (rp[r].ok) {
-        replay(0u, cnt[r], [&](uint32_t k, uint32_t id) {
+      if (rp.ok) {
+        replay(0u, cnt, [&](uint32_t k, uint32_t id) {
           if (pos + k < cap) hits[pos + k] = id;
         });
-        qy[r].nseg = 0;
+        qy.nseg = 0;
       }
       if (!all_replay)
-        (void)enumerate_hits<Mode::Fill, F, false, kKeep, kRowsN>(v, segs, qy[r], hits, pos, cap, nullptr);
+        (void)enumerate_hits<Mode::Fill, F, false, kKeep, kRowsN>(v, segs, qy, hits, pos, cap, nullptr);
       if (S) {  // a wavefront with general-path queries: sort what it has just written (lists cut by `cap` stay cut)
         wave_sync_mem();
-        const uint64_t e = pos + cnt[r];
+        const uint64_t e = pos + cnt;
         wave_sort_lists<kStage, kFusedRankBlock>(s_out[wave], pos < cap ? pos : cap, e < cap ? e : cap, hits, lane);
       }
     }
-    pos += cnt[r];
   }
   // self-cleaning workspace: every tile bumps `done` when it leaves (its sweep is long over); the tile that
   // sees gridDim.x - 1 knows nobody reads the words any more and zeroes them for the next launch. Off the
@@ -420,8 +428,6 @@ size_t fused_workspace_bytes(size_t q) {
   return ((size_t)kFMaxTiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t);
 }
 
-size_t fused_workspace_timeouts_offset() { return (size_t)kWsTimeouts * sizeof(uint64_t); }
-
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                        const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
                        void *d_ws, bool self_clean, bool sort_ids, hipStream_t s, uint32_t *d_counts,
@@ -450,7 +456,14 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
       BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
     const dim3 grid(tiles), block(kFThreads);
     const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
-    const int flags = (self_clean ? kFlagSelfClean : 0) | (q1 == q ? kFlagFinal : 0);
+    // BIVX_PREFIX_WAIT_LOG2 (tests): bound of a prefix wait as log2 of 10 ns ticks; 1 makes every wait that is not
+    // satisfied at once expire, which is how the error path is exercised
+    int wait_log2 = 0;
+    if (const char *e = std::getenv("BIVX_PREFIX_WAIT_LOG2")) {
+      const long w = std::atol(e);
+      if (w > 0 && w < 64) wait_log2 = (int)w;
+    }
+    const int flags = (self_clean ? kFlagSelfClean : 0) | (q1 == q ? kFlagFinal : 0) | (wait_log2 << kFlagWaitShift);
     // Ordering ids inside the kernel pays while a wavefront's 64 lists fit half its output stage (one round, all
     // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
     // ordered by k_sort_hits afterwards, whose stage is eight times larger.

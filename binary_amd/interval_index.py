@@ -116,8 +116,12 @@ class IntervalIndex:
         capi.check(self._L.bivx_get_intervals(self._h, _ptr(ids), ids.size, _ptr(c), _ptr(lo), _ptr(hi)))
         return c, lo, hi
 
-    def count_workspace_bytes(self, q: int) -> int:
-        return int(self._L.bivx_count_workspace_bytes(int(q)))
+    def stream_status(self, stream=None) -> None:
+        """Synchronises `stream` (default: torch's current stream on the index's device) and raises BivxError
+        (code capi.E_TIMEOUT) if a single-pass kernel of this index reported an invalid result since the last check."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream if torch is not None else 0
+        capi.check(self._L.bivx_stream_status(self._h, C.c_void_p(stream)))
 
     def _ensure_built(self):
         if not self._L.bivx_is_built(self._h):
@@ -156,7 +160,7 @@ class IntervalIndex:
         return first
 
     # ---- query side, device tensors (no host round trip except the hit total) --------------------------
-    def count_overlaps_device(self, qlow, qhigh, qchrom=None, offsets=None, workspace=None):
+    def count_overlaps_device(self, qlow, qhigh, qchrom=None, offsets=None):
         """offsets int64[q+1] on the device (exclusive prefix of hit counts); asynchronous."""
         self._ensure_built()
         q = qlow.numel()
@@ -167,10 +171,9 @@ class IntervalIndex:
         if offsets is None:
             offsets = torch.empty(q + 1, dtype=torch.int64, device=qlow.device)
         _check_dev_tensor(offsets, "offsets", q + 1, 8)
-        # `workspace` is accepted for compatibility; bivx_count_dev needs no caller scratch since ABI 1.3
         s = torch.cuda.current_stream(qlow.device).cuda_stream
         capi.check(self._L.bivx_count_dev(self._h, _tptr(qchrom), _tptr(qlow), _tptr(qhigh), q, _tptr(offsets),
-                                          None, 0, C.c_void_p(s)))
+                                          C.c_void_p(s)))
         return offsets
 
     def fill_overlaps_device(self, qlow, qhigh, offsets, hits, qchrom=None, sort_by_id: bool = False):

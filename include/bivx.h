@@ -41,14 +41,17 @@ typedef enum bivx_status {
   BIVX_E_HIP = -2,     /* a HIP runtime call failed (text in bivx_last_error) */
   BIVX_E_NOMEM = -3,   /* host allocation failed */
   BIVX_E_STATE = -4,   /* e.g. query before build */
-  BIVX_E_RANGE = -5    /* too many intervals (>= 2^32-1) or chromosome ids (> BIVX_MAX_CHROMS) */
+  BIVX_E_RANGE = -5,   /* too many intervals (>= 2^32-1) or chromosome ids (> BIVX_MAX_CHROMS) */
+  BIVX_E_TIMEOUT = -6  /* a single-pass query kernel gave up a bounded cross-workgroup wait, or found its prefix
+                          workspace in an inconsistent state: the CSR of that call is INVALID (never returned with
+                          rc 0); the index stays usable, repeat the call */
 } bivx_status;
 
 #define BIVX_MAX_CHROMS 65536u
 #define BIVX_NO_HIT 0xFFFFFFFFu
 
 /* ABI version of this header: major << 16 | minor. */
-#define BIVX_ABI_VERSION 0x00010003u
+#define BIVX_ABI_VERSION 0x00020000u
 uint32_t bivx_abi_version(void);
 const char *bivx_last_error(void);
 
@@ -111,14 +114,12 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
 void bivx_free(void *p);
 
 /* device-resident variants. bivx_count_dev is one launch of the single-pass kernel with a zero-capacity hit
- * buffer (it counts, chains the prefix across workgroups and writes d_offsets[q + 1]); since ABI 1.3 it needs no
- * caller scratch: bivx_count_workspace_bytes returns 0 and d_workspace / workspace_bytes are ignored. Like
- * bivx_query_dev without a caller workspace it uses the index's per-stream workspace, which the first call on a
- * stream allocates: make that call before capturing the stream into a graph. */
-size_t bivx_count_workspace_bytes(size_t q);
+ * buffer (it counts, chains the prefix across workgroups and writes d_offsets[q + 1]); it needs no caller scratch
+ * (ABI 2.0 dropped the workspace arguments it had ignored since 1.3). Like bivx_query_dev without a caller
+ * workspace it uses the index's per-stream workspace, which the first call on a stream allocates: make that call
+ * before capturing the stream into a graph (inside a capture it fails with BIVX_E_STATE). */
 int bivx_count_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
-                   const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, void *d_workspace,
-                   size_t workspace_bytes, void *stream);
+                   const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, void *stream);
 int bivx_fill_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                   const uint32_t *d_qhigh, size_t q, const uint64_t *d_offsets, uint32_t *d_hit_ids,
                   void *stream);
@@ -132,6 +133,16 @@ size_t bivx_query_workspace_bytes(size_t q);
 int bivx_query_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                    const uint32_t *d_qhigh, size_t q, uint64_t *d_offsets, uint32_t *d_hit_ids,
                    uint64_t hit_capacity, void *d_workspace, size_t workspace_bytes, void *stream);
+/* Error state of the asynchronous entry points. The single-pass kernels (bivx_query_dev*, bivx_count_dev*) chain a
+ * prefix across workgroups; a workgroup whose bounded wait for a predecessor expires (about 20 s: the device
+ * stopped making progress), or that finds the prefix workspace inconsistent, raises a sticky flag instead of
+ * hanging. bivx_stream_status synchronises `stream`, returns BIVX_E_TIMEOUT if a flag was raised by any call on
+ * this index since the last report (that call's CSR is invalid) and clears it, else 0. The host-pointer entry
+ * points (bivx_count*, bivx_fill*, bivx_find_overlaps) make the same check before they return, so they never hand
+ * out such a result with rc 0 (reference analogue: none, the CPU tree cannot fail this way; SURVEY.md §5 asks
+ * that every status is surfaced). */
+int bivx_stream_status(const bivx_index *idx, void *stream);
+
 /* sorts every query's hit list ascending by id, in place */
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q,
                        void *stream);
@@ -178,8 +189,7 @@ int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *
 int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                 size_t q, const bivx_filter *filter, const uint64_t *offsets, uint32_t *hit_ids_out, int sort_by_id);
 int bivx_count_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
-                     const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, uint64_t *d_offsets,
-                     void *d_workspace, size_t workspace_bytes, void *stream);
+                     const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, uint64_t *d_offsets, void *stream);
 int bivx_fill_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t *d_qlow,
                     const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, const uint64_t *d_offsets,
                     uint32_t *d_hit_ids, void *stream);
@@ -209,6 +219,11 @@ int bivx_query_dev_u(const bivx_index *idx, const uint32_t *d_qchrom, const uint
                      uint32_t *d_count, uint32_t *d_hit_ids, uint64_t hit_capacity, uint64_t *d_total,
                      void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Testing hook (tests/test_gpu_errors.py): overwrites the ticket word of the prefix workspace the index keeps for
+ * `stream`, as a launch that died half-way would leave it, so that the next single-pass call on that stream finds
+ * it inconsistent and the error path above can be exercised. Not for production use. */
+int bivx_debug_corrupt_workspace(const bivx_index *idx, void *stream);
+
 /* ---- introspection (bench / DESIGN.md numbers) -------------------------------------------------- */
 typedef struct bivx_stats {
   uint64_t n_intervals;
@@ -218,9 +233,8 @@ typedef struct bivx_stats {
   uint64_t index_bytes;     /* device bytes of the built index (sorted arrays + directory) */
   uint64_t staging_bytes;   /* device bytes of the append-order copy */
   double build_ms;          /* wall time of the last bivx_build */
-  uint64_t prefix_timeouts; /* bounded cross-workgroup waits of bivx_query_dev (index-owned workspace) that gave up since
-                               the last build; 0 unless the device stopped making progress — results of such a call
-                               are invalid. Reading it synchronises the device. */
+  uint64_t prefix_timeouts; /* calls on this index reported with BIVX_E_TIMEOUT since it was created (plus one while a
+                               raised flag waits to be reported); bivx_build does not reset it */
 } bivx_stats;
 int bivx_get_stats(const bivx_index *idx, bivx_stats *out);
 

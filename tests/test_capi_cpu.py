@@ -33,7 +33,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.bivx_abi_version() == 0x00010003
+    assert lib.bivx_abi_version() == 0x00020000
 
 
 def test_code_object_is_gfx950(lib, tmp_path):

@@ -26,8 +26,7 @@ def test_config5_whole_genome_self_overlap_50M(oracle):
         build_s = time.perf_counter() - t0
         st = idx.stats()
         off = torch.empty(N + 1, dtype=torch.int64, device=dev)
-        ws = torch.empty(idx.count_workspace_bytes(N), dtype=torch.uint8, device=dev)
-        idx.count_overlaps_device(d_lo, d_hi, d_c, offsets=off, workspace=ws)
+        idx.count_overlaps_device(d_lo, d_hi, d_c, offsets=off)
         H = int(off[-1].item())
         assert 0.7e9 < H < 1.0e9          # SURVEY §8d expects about 0.81 G
         hits = torch.empty(H, dtype=torch.int32, device=dev)

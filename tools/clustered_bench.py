@@ -18,8 +18,7 @@ to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
 idx = IntervalIndex(0); idx.insert_node(low, high); idx.build()
 dql, dqh = to(qlo), to(qhi)
 off = torch.empty(qlo.size + 1, dtype=torch.int64, device=dev)
-ws = torch.empty(idx.count_workspace_bytes(qlo.size), dtype=torch.uint8, device=dev)
-idx.count_overlaps_device(dql, dqh, offsets=off, workspace=ws)
+idx.count_overlaps_device(dql, dqh, offsets=off)
 H = int(off[-1].item())
 hits = torch.empty(H, dtype=torch.int32, device=dev)
 def timed(fn, reps=20):
@@ -30,4 +29,4 @@ def timed(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-print(f"H={H}  single-pass {timed(lambda: idx.query_device(dql, dqh, off, hits)):.3f} ms   count {timed(lambda: idx.count_overlaps_device(dql, dqh, offsets=off, workspace=ws)):.3f} ms")
+print(f"H={H}  single-pass {timed(lambda: idx.query_device(dql, dqh, off, hits)):.3f} ms   count {timed(lambda: idx.count_overlaps_device(dql, dqh, offsets=off)):.3f} ms")

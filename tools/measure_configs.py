@@ -49,13 +49,12 @@ def run_config(name, data, reps):
             perm = np.arange(Q)
         qc, ql, qh = to(data["qchrom"][perm]), to(data["qlow"][perm]), to(data["qhigh"][perm])
         off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
-        ws = torch.empty(idx.count_workspace_bytes(Q), dtype=torch.uint8, device=dev)
         qws = torch.empty(idx.query_workspace_bytes(Q), dtype=torch.uint8, device=dev)
-        idx.count_overlaps_device(ql, qh, qc, offsets=off, workspace=ws)
+        idx.count_overlaps_device(ql, qh, qc, offsets=off)
         H = int(off[-1].item())
         hits = torch.empty(max(H, 1), dtype=torch.int32, device=dev)
         ms1 = timed(lambda: idx.query_device(ql, qh, off, hits, qws, qchrom=qc), reps)
-        ms2 = timed(lambda: (idx.count_overlaps_device(ql, qh, qc, offsets=off, workspace=ws),
+        ms2 = timed(lambda: (idx.count_overlaps_device(ql, qh, qc, offsets=off),
                              idx.fill_overlaps_device(ql, qh, off, hits, qchrom=qc)), reps)
         ms3 = timed(lambda: idx.query_device(ql, qh, off, hits, qws, qchrom=qc, sort_by_id=True), reps)
         beg = torch.empty(Q, dtype=torch.int64, device=dev)

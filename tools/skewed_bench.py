@@ -20,8 +20,7 @@ idx = IntervalIndex(0); idx.insert_node(low, high); idx.build()
 st = idx.stats()
 dq = to(qlo)
 off = torch.empty(q + 1, dtype=torch.int64, device=dev)
-ws = torch.empty(idx.count_workspace_bytes(q), dtype=torch.uint8, device=dev)
-idx.count_overlaps_device(dq, dq, offsets=off, workspace=ws)
+idx.count_overlaps_device(dq, dq, offsets=off)
 H = int(off[-1].item())
 hits = torch.empty(H, dtype=torch.int32, device=dev)
 def timed(fn, reps=10):
@@ -33,6 +32,6 @@ def timed(fn, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 t = timed(lambda: idx.query_device(dq, dq, off, hits))
-t2 = timed(lambda: idx.count_overlaps_device(dq, dq, offsets=off, workspace=ws))
+t2 = timed(lambda: idx.count_overlaps_device(dq, dq, offsets=off))
 print(f"maxlen={MAXLEN} count-only {t2:.3f} ms;", end=" ")
 print(f"segments={st['n_segments']} build_ms={st['build_ms']:.2f} H={H} ({H/q:.1f} hits/query) single-pass {t:.3f} ms = {q/t/1e6:.2f} G q/s, {H/t/1e6:.2f} G hits/s")
