@@ -17,6 +17,8 @@ constexpr uint32_t kLight = 64;      // window slots a lane reads by itself; lon
 #endif
 constexpr uint32_t kTrim = BIVX_TRIM;  // wavefront windows longer than this are first trimmed by a 64-ary search
 constexpr uint32_t kRows = 4;        // rows of 64 slots (and their ids) the wavefront-cooperative path keeps in flight
+constexpr uint32_t kSlabSlots = 256;  // candidate slots a wavefront stages through LDS when its 64 windows are neighbours
+constexpr uint32_t kSlabMinLanes = 32;  // ... and at least this many of its lanes' windows fit the slab
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
 constexpr uint32_t kLdsChroms = 511; // ... with chrom_seg (2 KiB); larger indexes read them from global
 
@@ -63,6 +65,11 @@ __device__ __forceinline__ Window seg_window(const IndexView &v, const SegDesc &
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, kWave);
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x = max(x, (uint32_t)__shfl_xor(x, d, kWave));
   return x;
 }
 __device__ __forceinline__ uint32_t wave_min(uint32_t x) {
@@ -199,6 +206,31 @@ __device__ __forceinline__ uint64_t light_mask_packed(const IndexView &v, const 
   return mask;
 }
 
+// The same out of the wavefront's LDS slab: slab[i] holds the record pair of slots lbase + 2i, lbase + 2i + 1
+// (lbase even). Used when the 64 windows of a wavefront are neighbours in the index — a position-sorted batch — so
+// that every line of records is fetched from memory once per wavefront, with coalesced 16-byte loads, instead of
+// once per query (reference loop replaced: one find_overlaps per record in file order, mapper.hpp:202-236).
+template <bool F>
+__device__ __forceinline__ uint64_t light_mask_packed_lds(const IndexView &v, const uint4 *slab, uint32_t lbase,
+                                                          const Window &w, uint32_t lo, uint32_t hi, uint32_t qaux,
+                                                          uint32_t &al) {
+  al = w.a & ~1u;
+  uint64_t mask = 0;
+  uint32_t n = 0;
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < kLight; c0 += 8) {
+    if (al + c0 < w.b) {
+      uint4 r[4];
+      const uint32_t c = al + c0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + 2 * j < w.b) r[j] = slab[((c - lbase) >> 1) + j];
+      mask |= (uint64_t)packed_eval_chunk<F, kKeep>(v, w, lo, hi, qaux, c, r, nullptr, n) << c0;
+    }
+  }
+  return mask;
+}
+
 // First slot in [a, b) whose low is >= x (b if there is none), found by the whole wavefront: a 64-ary search — the
 // 64 lanes probe 64 evenly spaced slots, one __ballot tells which gap holds the answer, repeat. Used to trim long
 // candidate windows (many intervals starting inside one directory cell) to the slots whose low lies in
@@ -228,6 +260,16 @@ __device__ __forceinline__ void wave_sync_mem() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// the same for LDS traffic only: one wavefront's LDS instructions execute in order, so all it takes is that the
+// compiler keeps the order too (the full form above also waits for the wavefront's outstanding global stores,
+// which an output stage that is refilled in rounds must not do)
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 enum class Mode { Count, Fill, Any };
 
 // Per-lane query state shared by every kernel.
@@ -245,6 +287,8 @@ struct Replay {
   bool ok;
   bool kept;      // ids of the first min(hits, KEEP) hits were written to the caller's `keep` slots
   bool packed;    // the window was read from packed records: ids sit in rec[].y
+  bool lds;       // ... out of the wavefront's LDS slab, where they still are: slot s is slab2[s - lbase]
+  uint32_t lbase; // first slot of the slab (wavefront-uniform)
   uint32_t nrec;  // windows recorded (those with hits): the first one above, later ones in the lane's LDS slots
 };
 // A query over several segments (several length classes on its chromosome) records up to kMaxRec windows: the
@@ -256,10 +300,13 @@ constexpr uint32_t kMaxRec = 3;
 //   Count: returns the number of hits (and fills *rp).   Any: returns the smallest hit id (BIVX_NO_HIT if none).
 //   Fill:  writes hit ids to hits_base[dst_pos ..), in index order, only positions below `cap`;
 //          returns the number of hits.
-template <Mode M, bool F, bool MS = false, uint32_t KEEP = kKeep, uint32_t kHeavyRows = kRows>
+//   SLAB (Count only, one segment per chromosome): `slab` is kSlabSlots * 8 bytes of LDS owned by the calling
+//          wavefront; it may alias the 64 lanes' `keep` slots (a wavefront that fills the slab keeps no ids there).
+template <Mode M, bool F, bool MS = false, uint32_t KEEP = kKeep, uint32_t kHeavyRows = kRows, bool SLAB = false>
 __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const SegDesc *segs, const Query &qy,
                                                    uint32_t *hits_base, uint64_t dst_pos, uint64_t cap,
-                                                   Replay *rp, uint32_t *keep = nullptr, uint32_t *xrec = nullptr) {
+                                                   Replay *rp, uint32_t *keep = nullptr, uint32_t *xrec = nullptr,
+                                                   uint4 *slab = nullptr) {
   const int lane = threadIdx.x & (kWave - 1);
   uint32_t acc = (M == Mode::Any) ? BIVX_NO_HIT : 0u;
   const uint32_t lo = qy.lo, hi = qy.hi;
@@ -269,10 +316,13 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
     rp->ok = MS || qy.nseg <= 1;
     rp->kept = false;
     rp->packed = false;
+    rp->lds = false;
+    rp->lbase = 0;
     rp->nrec = 0;
   }
   // the segment loop is wavefront-uniform so the cooperative part may use __ballot / __shfl
-  for (uint32_t k = 0; __any(k < qy.nseg); ++k) {
+  // (kernels built for indexes with one segment per chromosome make a single trip)
+  for (uint32_t k = 0; MS || M != Mode::Count ? __any(k < qy.nseg) : k < 1u; ++k) {
     Window w{0u, 0u, 0u, 0u, false};
     uint32_t shf = 0, xlow = 0;
     if (k < qy.nseg) {
@@ -284,11 +334,33 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
     const bool nonempty = w.span != 0 && w.b > w.a;
     const bool packed = (shf & kSegPacked) != 0 && w.narrow;
     const bool heavy = nonempty && (w.b - (w.a & ~1u)) > kLight;
+    // Neighbouring windows (a position-sorted batch): the wavefront fetches the union of its windows once, with
+    // coalesced 16-byte loads, into its LDS slab; the lanes then read their windows — and later the ids of their
+    // hits — from there. Decided per wavefront from the windows themselves, so it needs no hint from the caller:
+    // a wavefront whose windows are scattered (queries in arbitrary order) keeps the per-lane loads below.
+    bool in_slab = false, slab_on = false;
+    uint32_t lbase = 0;
+    if (SLAB && M == Mode::Count) {
+      const bool cand = nonempty && !heavy && packed;
+      lbase = __builtin_amdgcn_readfirstlane(wave_min(cand ? (w.a & ~1u) : 0xFFFFFFFFu));
+      in_slab = cand && w.b - lbase <= kSlabSlots;
+      slab_on = (uint32_t)__popcll(__ballot(in_slab)) >= kSlabMinLanes;
+      if (slab_on) {
+        const uint32_t bmax = __builtin_amdgcn_readfirstlane(wave_max(in_slab ? w.b : 0u));
+        const uint32_t npairs = (bmax - lbase + 1) >> 1;  // <= kSlabSlots / 2; rec[] carries two spare slots
+        const uint4 *src = reinterpret_cast<const uint4 *>(v.rec) + (lbase >> 1);
+        for (uint32_t i = (uint32_t)lane; i < npairs; i += kWave) slab[i] = src[i];
+        wave_sync_lds();
+      }
+      in_slab = in_slab && slab_on;
+    }
     if (nonempty && !heavy) {
       uint32_t al;
       uint64_t mask;
-      const bool want = M == Mode::Count && packed && keep != nullptr && qy.nseg == 1;
-      if (packed) {
+      const bool want = M == Mode::Count && packed && keep != nullptr && qy.nseg == 1 && !slab_on;
+      if (SLAB && in_slab) {
+        mask = light_mask_packed_lds<F>(v, slab, lbase, w, lo, hi, qy.aux, al);
+      } else if (packed) {
         mask = light_mask_packed<F, KEEP>(v, w, lo, hi, qy.aux, al, want ? keep : nullptr);
       } else {
         mask = light_mask_pairs<F>(v, w.a, w.b, lo, hi, qy.aux, al);
@@ -301,6 +373,8 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
             rp->mask = mask;
             rp->kept = want;
             rp->packed = packed;
+            rp->lds = SLAB && in_slab;
+            rp->lbase = lbase;
           } else if (rp->nrec < kMaxRec) {
             uint32_t *slot = rp->nrec == 1 ? keep : xrec;
             slot[0] = al | (packed ? 1u : 0u);

@@ -29,6 +29,9 @@ namespace {
 #define BIVX_FUSED_THREADS 1024
 #endif
 constexpr int kFThreads = BIVX_FUSED_THREADS;
+#ifndef BIVX_FUSED_WAVES
+#define BIVX_FUSED_WAVES 8  // waves per SIMD the register allocation is held to: 8 = two workgroups per CU, 64 VGPRs
+#endif
 constexpr int kFWaves = kFThreads / kWave;
 // One query per thread. (More per thread was measured and did not pay: a wavefront here is latency-bound, and the
 // output staging below relies on the 64 lists of a wavefront being adjacent.)
@@ -74,9 +77,10 @@ __device__ __forceinline__ void st_status(uint64_t *p, uint64_t w) {
 // buffer no other code reads; the product build has no stamp.
 #ifdef BIVX_STAMPS
 constexpr unsigned kStampTiles = 1024;
-__device__ unsigned long long g_stamps[kStampTiles * 8];
+constexpr unsigned kStampSlots = 12;
+__device__ unsigned long long g_stamps[kStampTiles * kStampSlots];
 #define BIVX_STAMP(k) \
-  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kStampTiles) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kStampTiles) * kStampSlots + (k)] = __builtin_amdgcn_s_memrealtime()
 #else
 #define BIVX_STAMP(k)
 #endif
@@ -89,7 +93,7 @@ __device__ unsigned long long g_stamps[kStampTiles * 8];
 //    (q words) and `counts` count[q]; ranges of different tiles lie in the buffer in whatever order the tiles
 //    got there, inside a tile they are in query order. The last tile to leave stores the total in *total_out.
 template <bool LDS_DESC, bool F, bool S, bool MS, bool U>
-__global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
+__global__ __launch_bounds__(kFThreads, BIVX_FUSED_WAVES) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
                                                            const uint32_t *__restrict__ qhigh, size_t q_begin,
                                                            size_t q_end, uint64_t *__restrict__ offsets,
@@ -145,7 +149,12 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   Replay rp;
   uint32_t *const kept = reinterpret_cast<uint32_t *>(&s_keep[threadIdx.x * (kKeepN / 4)]);
   uint32_t *const xrec = reinterpret_cast<uint32_t *>(&s_xrec[MS ? threadIdx.x : 0]);
-  const uint32_t cnt = enumerate_hits<Mode::Count, F, MS, kKeepN, kRowsN>(v, segs, qy, nullptr, 0, 0, &rp, kept, xrec);
+  // the wavefront's slab for neighbouring windows: the 64 lanes' keep slots taken together (2 KiB = kSlabSlots
+  // records); only the kernels whose chromosomes have one segment each use it
+  constexpr bool kSlab = !MS && kKeepN * 4 * kWave >= kSlabSlots * 8;
+  uint4 *const slab = &s_keep[(threadIdx.x & ~(kWave - 1)) * (kKeepN / 4)];
+  const uint32_t cnt = enumerate_hits<Mode::Count, F, MS, kKeepN, kRowsN, kSlab>(v, segs, qy, nullptr, 0, 0, &rp, kept,
+                                                                              xrec, slab);
   const uint32_t tsum = cnt;
 
   BIVX_STAMP(2);
@@ -275,6 +284,15 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
     uint32_t cur_al = rp.al, cur_rec = 1;
     bool cur_packed = rp.packed;
     auto replay = [&](uint32_t k0, uint32_t k1, auto put) {
+      if (kSlab && rp.lds) {  // every id is in the wavefront's LDS slab: there are no loads to batch
+        const uint2 *s2 = reinterpret_cast<const uint2 *>(slab) + (rp.al - rp.lbase);
+        for (uint32_t k = k0; k < k1; ++k) {
+          const uint32_t j = (uint32_t)__ffsll((long long)mrem) - 1u;
+          mrem &= mrem - 1;
+          put(k, s2[j].y);
+        }
+        return;
+      }
       for (uint32_t k = k0; k < k1; k += kGather) {
         uint32_t slot[kGather], ids[kGather], pk = 0;
 #pragma unroll
@@ -331,15 +349,15 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
         const bool mine = (uint32_t)lane >= first && (uint32_t)lane < next && cnt != 0;
         const uint32_t rel = loff - base;
         if (mine) replay(0u, cnt, [&](uint32_t k, uint32_t id) { in[rel + k] = id; });
-        wave_sync_mem();
+        wave_sync_lds();
         if (mine) rank_sort_list<kFusedRankBlock>(in, outb, rel, cnt);
-        wave_sync_mem();
+        wave_sync_lds();
         const uint32_t nthis = __shfl(loff + cnt, (int)next - 1, kWave) - base;
         for (uint32_t i = lane; i < nthis; i += kWave) {
           const uint64_t p = wpos0 + base + i;
           if (p < cap) hits[p] = outb[i];
         }
-        wave_sync_mem();
+        wave_sync_lds();
         first = next;
       }
     } else if (all_replay && wtotal >= kStageMin) {
@@ -352,13 +370,13 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
           replay(kdone, kend, [&](uint32_t k, uint32_t id) { buf[loff + k - base] = id; });
           kdone = kend;
         }
-        wave_sync_mem();
+        wave_sync_lds();
         const uint32_t nthis = wtotal - base < kStage ? wtotal - base : kStage;
         for (uint32_t i = lane; i < nthis; i += kWave) {
           const uint64_t p = wpos0 + base + i;
           if (p < cap) hits[p] = buf[i];
         }
-        wave_sync_mem();
+        wave_sync_lds();
       }
     } else {
       // few ids per lane (or a wavefront that holds general-path queries): every lane stores its own list
@@ -377,6 +395,7 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
       }
     }
   }
+  BIVX_STAMP(8);   // wave 0 is through with its ids
   // self-cleaning workspace: every tile bumps `done` when it leaves (its sweep is long over); the tile that
   // sees gridDim.x - 1 knows nobody reads the words any more and zeroes them for the next launch. Off the
   // critical path: nothing waits for this but the end of the kernel.
@@ -397,7 +416,9 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
         s_last = 1;
       }
     }
+    BIVX_STAMP(9);   // departure counted
     __syncthreads();
+    BIVX_STAMP(10);  // all sixteen wavefronts are through
     if (s_last) {
       if (!U)
         for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) {
@@ -417,7 +438,7 @@ __global__ __launch_bounds__(kFThreads, 8) void k_query_fused(IndexView v, const
   }
   BIVX_STAMP(6);
 #ifdef BIVX_STAMPS
-  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kStampTiles) * 8 + 7] = tile;
+  if (threadIdx.x == 0) g_stamps[(blockIdx.x % kStampTiles) * kStampSlots + 7] = tile;
 #endif
 }
 
@@ -482,6 +503,9 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
   } else {                                                 \
     BIVX_LAUNCH_FUSED_V(L, FL, SO, false, false);          \
   }
+#ifdef BIVX_ONLY_MAIN  // development builds (tools/resource_usage.py): only the headline instantiation
+    BIVX_LAUNCH_FUSED_V(true, false, false, false, false);
+#else
     switch ((lds ? 4 : 0) | (flt ? 2 : 0) | (sort_inside ? 1 : 0)) {
       case 0: BIVX_LAUNCH_FUSED(false, false, false); break;
       case 1: BIVX_LAUNCH_FUSED(false, false, true); break;
@@ -492,6 +516,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
       case 6: BIVX_LAUNCH_FUSED(true, true, false); break;
       default: BIVX_LAUNCH_FUSED(true, true, true); break;
     }
+#endif
 #undef BIVX_LAUNCH_FUSED
 #undef BIVX_LAUNCH_FUSED_V
     if (sort_ids && !sort_inside && !unordered) {
@@ -505,7 +530,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
 
 #ifdef BIVX_STAMPS
 extern "C" int bivx_debug_stamps(unsigned long long *out, size_t n) {
-  if (n > (size_t)kStampTiles * 8) n = (size_t)kStampTiles * 8;
+  if (n > (size_t)kStampTiles * kStampSlots) n = (size_t)kStampTiles * kStampSlots;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
