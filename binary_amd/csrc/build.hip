@@ -101,9 +101,9 @@ __global__ __launch_bounds__(kThreads) void k_make_segkeys(const uint32_t *__res
 
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
-constexpr int kRounds = 16;
+constexpr int kRounds = 4;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kTile = kThreads * kRounds;  // 4096 keys
+constexpr int kTile = kThreads * kRounds;  // 1024 keys (more rounds per thread cost ~20 VGPRs each: 16 took 256)
 
 __device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid) {
   uint64_t m = __ballot(valid);

@@ -45,8 +45,11 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
 }
 
 __global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restrict__ offsets,
-                                                         uint32_t *__restrict__ hits, size_t nq, uint64_t cap) {
+                                                         uint32_t *__restrict__ hits, size_t nq, uint64_t cap,
+                                                         const uint32_t *__restrict__ cond, uint32_t seq) {
   __shared__ uint32_t lds[kQWaves][kSortLds];
+  // conditional form: the single-pass kernel ordered the ids itself unless one of its wavefronts said otherwise
+  if (cond && __hip_atomic_load(cond, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) return;
   const size_t q = (size_t)blockIdx.x * kQThreads + threadIdx.x;
   uint64_t o0, o1;
   if (q < nq) {
@@ -91,9 +94,10 @@ int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_q
   return launch_query<Mode::Any>(v, d_qchrom, d_qlow, d_qhigh, q, nullptr, d_first, s);
 }
 
-int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, uint64_t cap, hipStream_t s) {
+int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, uint64_t cap, hipStream_t s,
+                     const uint32_t *d_cond, uint32_t seq) {
   if (q == 0) return 0;
-  hipLaunchKernelGGL(k_sort_hits, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q, cap);
+  hipLaunchKernelGGL(k_sort_hits, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q, cap, d_cond, seq);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

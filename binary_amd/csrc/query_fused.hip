@@ -3,6 +3,7 @@
 // ordered inside the kernel), bivx_query_dev_u (per-query begin/count, no cross-workgroup wait) and
 // bivx_count_dev (zero-capacity buffer). Replaces a batch of IntervalTree::find_overlaps calls (reference
 // interval_tree.hpp:306-334). Device building blocks: query_device.h.
+#include <atomic>
 #include <cstdlib>
 
 #include "query_device.h"
@@ -43,7 +44,7 @@ constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per roun
 #ifndef BIVX_GATHER
 #define BIVX_GATHER 8
 #endif
-constexpr uint32_t kGather = BIVX_GATHER;  // ids a lane fetches per step when it replays a window in phase 2
+constexpr uint32_t kGatherMax = BIVX_GATHER;  // ids a lane fetches per step when it replays a window in phase 2
 static_assert(kMaxRec * kLight <= kStage / 2, "a replayed list must fit half the output stage");
 #ifndef BIVX_STAGE_MIN
 #define BIVX_STAGE_MIN 128
@@ -52,7 +53,9 @@ constexpr uint32_t kStageMin = BIVX_STAGE_MIN;  // ... when it has at least this
 constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
 // on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
-constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsStatus = 32;
+constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsNeedSort = 24, kWsStatus = 32;
+// ws[kWsNeedSort]: sequence number of the last launch that left lists for k_sort_hits to order (never cleared:
+// every launch carries a fresh number)
 constexpr uint32_t kDoneShift = 44;  // unordered output: ws[kWsDone] = departures << 44 | ids reserved by this launch
 // k_query_fused flags: index-owned workspace; last launch of the call; bits 8-15: log2 of the bound on a prefix
 // wait in ticks of the 100 MHz constant clock (0 = kWaitLog2Default)
@@ -93,14 +96,16 @@ __device__ unsigned long long g_stamps[kStampTiles * kStampSlots];
 //    (q words) and `counts` count[q]; ranges of different tiles lie in the buffer in whatever order the tiles
 //    got there, inside a tile they are in query order. The last tile to leave stores the total in *total_out.
 template <bool LDS_DESC, bool F, bool S, bool MS, bool U>
-__global__ __launch_bounds__(kFThreads, BIVX_FUSED_WAVES) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
+// (the filtered variants carry the filter's words on top: they are built for 4 waves per SIMD, one workgroup per CU,
+//  which is what keeps them out of scratch; sv2nl batches are 1e4 - 1e5 records)
+__global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_fused(IndexView v, const uint32_t *__restrict__ qchrom,
                                                            const uint32_t *__restrict__ qlow,
                                                            const uint32_t *__restrict__ qhigh, size_t q_begin,
                                                            size_t q_end, uint64_t *__restrict__ offsets,
                                                            uint32_t *__restrict__ hits, uint64_t cap,
                                                            uint64_t *__restrict__ ws, int flags,
                                                            uint32_t *__restrict__ counts,
-                                                           uint64_t *__restrict__ total_out) {
+                                                           uint64_t *__restrict__ total_out, uint32_t seq) {
   const bool self_clean = (flags & kFlagSelfClean) != 0;
   __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
   __shared__ uint32_t s_cs[LDS_DESC ? kLdsChroms + 1 : 1];
@@ -116,6 +121,9 @@ __global__ __launch_bounds__(kFThreads, BIVX_FUSED_WAVES) void k_query_fused(Ind
   // rows the wavefront-cooperative path keeps in flight: the id-ordering variants are the tightest on registers
   // (four rows cost them 8 more bytes of scratch per lane and 4 % on configs 2-3)
   constexpr uint32_t kRowsN = S ? 1 : kRows;
+  // ids fetched per replay step: the variants that carry more state (several recorded windows, id ordering, filter
+  // words) fetch four, which is what keeps every one of them inside 64 VGPRs / 80 SGPRs without scratch
+  constexpr uint32_t kGather = (MS || S || F) && kGatherMax > 4 ? 4 : kGatherMax;
   __shared__ uint4 s_keep[kFThreads * (kKeepN / 4)];
   __shared__ uint32_t s_out[kFWaves][kStage];  // per-wavefront staging of the output ids
   __shared__ uint4 s_xrec[MS ? kFThreads : 1];  // a query's third recorded window (thread-private slots)
@@ -388,11 +396,11 @@ __global__ __launch_bounds__(kFThreads, BIVX_FUSED_WAVES) void k_query_fused(Ind
       }
       if (!all_replay)
         (void)enumerate_hits<Mode::Fill, F, false, kKeep, kRowsN>(v, segs, qy, hits, pos, cap, nullptr);
-      if (S) {  // a wavefront with general-path queries: sort what it has just written (lists cut by `cap` stay cut)
-        wave_sync_mem();
-        const uint64_t e = pos + cnt;
-        wave_sort_lists<kStage, kFusedRankBlock>(s_out[wave], pos < cap ? pos : cap, e < cap ? e : cap, hits, lane);
-      }
+      // A wavefront with general-path queries wrote its lists in index order. Ordering them here would pull the
+      // whole bitonic machinery into this kernel (12-20 bytes of scratch per lane in every S variant); it asks the
+      // conditional k_sort_hits launch that follows this kernel to do it instead (rare: long windows only).
+      if (S && lane == 0)
+        __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + kWsNeedSort), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   BIVX_STAMP(8);   // wave 0 is through with its ids
@@ -489,9 +497,12 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
     // ordered by k_sort_hits afterwards, whose stage is eight times larger.
     const bool sort_inside = sort_ids && !unordered && cap <= (uint64_t)kFusedSortMaxAvg * q;
+    static std::atomic<uint32_t> launch_seq{1};
+    uint32_t seq = launch_seq.fetch_add(1);
+    if (seq == 0) seq = launch_seq.fetch_add(1);  // 0 is what a cleared workspace holds
 #define BIVX_LAUNCH_FUSED_V(L, FL, SO, MSV, UV)                                                               \
   hipLaunchKernelGGL((k_query_fused<L, FL, SO, MSV, UV>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, \
-                     q1, d_offsets, d_hits, cap, ws, flags, d_counts, d_total)
+                     q1, d_offsets, d_hits, cap, ws, flags, d_counts, d_total, seq)
 #define BIVX_LAUNCH_FUSED(L, FL, SO)                       \
   if (unordered) {                                         \
     if (v.max_segs > 1)                                    \
@@ -519,9 +530,12 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
 #endif
 #undef BIVX_LAUNCH_FUSED
 #undef BIVX_LAUNCH_FUSED_V
-    if (sort_ids && !sort_inside && !unordered) {
+    if (sort_ids && !unordered) {
       BIVX_HIP(hipGetLastError());
-      if (int rc = launch_sort_hits(d_offsets + q0, d_hits, q1 - q0, cap, s)) return rc;
+      // ordered inside the kernel: the pass only runs if a wavefront asked for it (it compares the word with seq)
+      if (int rc = launch_sort_hits(d_offsets + q0, d_hits, q1 - q0, cap, s,
+                                    sort_inside ? reinterpret_cast<const uint32_t *>(ws + kWsNeedSort) : nullptr, seq))
+        return rc;
     }
   }
   BIVX_HIP(hipGetLastError());

@@ -48,6 +48,24 @@ def test_code_object_is_gfx950(lib, tmp_path):
     assert not re.search(r"gfx(90a|942|1[0-9]{3})", out)
 
 
+def test_no_kernel_spills_to_scratch():
+    """Every kernel of libbivx.so keeps its state in registers: ScratchSize == 0 for every instantiation (round 1
+    shipped 19 of 24 single-pass variants with 12-60 bytes of scratch per lane), and the build-side scatter stays
+    under 128 VGPRs. From hipcc -Rpass-analysis=kernel-resource-usage (tools/resource_usage.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("resource_usage", os.path.join(ROOT, "tools", "resource_usage.py"))
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    rows = ru.usage()
+    fused = [r for r in rows if "k_query_fused" in r["name"]]
+    assert len(fused) == 24 and len(rows) >= 40
+    bad = [(r["name"], r["scratch"]) for r in rows if r["scratch"] != 0]
+    assert not bad, f"kernels with scratch: {bad}"
+    head = [r for r in fused if r["name"].endswith("<true, false, false, false, false>")][0]
+    assert head["vgpr"] <= 64 and head["occupancy"] == 8   # two workgroups of 1024 threads per CU
+    assert all(r["vgpr"] <= 128 for r in rows if "k_radix_scatter" in r["name"])
+
+
 def test_no_gpu_fails_loudly(lib):
     import torch
     if torch.cuda.is_available():
