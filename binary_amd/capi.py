@@ -15,7 +15,7 @@ ABI_VERSION = 0x00020000
 
 EXPORTS = (
     "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_destroy", "bivx_device", "bivx_append",
-    "bivx_append_dev", "bivx_clear", "bivx_build", "bivx_is_built", "bivx_size", "bivx_num_chroms",
+    "bivx_append_dev", "bivx_append_typed", "bivx_append_typed_dev", "bivx_num_types", "bivx_get_svtypes", "bivx_clear", "bivx_build", "bivx_is_built", "bivx_size", "bivx_num_chroms",
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
     "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f", "bivx_query_dev_s", "bivx_query_dev_u",
@@ -34,7 +34,7 @@ FILTER_NONE, FILTER_SV2NL_DUP, FILTER_SV2NL_INV, FILTER_SV2NL_TRA = 0, 1, 2, 3
 
 class Filter(C.Structure):
     """bivx_filter (include/bivx.h): fused sv2nl check_condition."""
-    _fields_ = [("kind", C.c_uint32), ("max_dist", C.c_uint32), ("use_strand", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("kind", C.c_uint32), ("max_dist", C.c_uint32), ("use_strand", C.c_uint32), ("svtype", C.c_uint32),
                 ("query_aux", C.c_void_p), ("interval_aux", C.c_void_p)]
 
 
@@ -65,6 +65,11 @@ def load() -> C.CDLL:
     L.bivx_device.argtypes = [vp]
     L.bivx_append.argtypes = [vp, u32p, u32p, u32p, sz]
     L.bivx_append_dev.argtypes = [vp, u32p, u32p, u32p, sz, vp]
+    L.bivx_append_typed.argtypes = [vp, u32p, u32p, u32p, vp, sz]
+    L.bivx_append_typed_dev.argtypes = [vp, u32p, u32p, u32p, vp, sz, vp]
+    L.bivx_num_types.argtypes = [vp]
+    L.bivx_num_types.restype = C.c_uint32
+    L.bivx_get_svtypes.argtypes = [vp, u32p, sz, vp]
     L.bivx_clear.argtypes = [vp]
     L.bivx_build.argtypes = [vp]
     L.bivx_is_built.argtypes = [vp]

@@ -76,6 +76,31 @@ __global__ __launch_bounds__(kThreads) void k_max_u32(const uint32_t *__restrict
   if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
 }
 
+__global__ __launch_bounds__(kThreads) void k_max_u8(const uint8_t *__restrict__ in, size_t n,
+                                                     uint32_t *__restrict__ out) {
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
+    m = max(m, (uint32_t)in[i]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, kWave));
+  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
+}
+
+// the (chromosome, svtype) partition id of every interval (include/bivx.h, bivx_append_typed)
+__global__ __launch_bounds__(kThreads) void k_make_vchrom(const uint32_t *__restrict__ chrom,
+                                                          const uint8_t *__restrict__ type, size_t n,
+                                                          uint32_t ntypes, uint32_t *__restrict__ vchrom) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) vchrom[i] = (chrom ? chrom[i] : 0u) * ntypes + type[i];
+}
+
+__global__ __launch_bounds__(kThreads) void k_gather_u8(const uint8_t *__restrict__ src,
+                                                        const uint32_t *__restrict__ ids, size_t n, size_t n_src,
+                                                        uint8_t *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) out[i] = ids[i] < n_src ? (src ? src[ids[i]] : (uint8_t)0) : (uint8_t)0xFF;
+}
+
 // ---- sort keys -----------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(kThreads) void k_make_segkeys(const uint32_t *__restrict__ chrom,
@@ -290,6 +315,31 @@ int launch_max_u32(const uint32_t *d_in, size_t n, uint32_t *d_out, hipStream_t 
   BIVX_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t), s));
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_max_u32, dim3(grid_for(n, kThreads * 8, 2048)), dim3(kThreads), 0, s, d_in, n, d_out);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_max_u8(const uint8_t *d_in, size_t n, uint32_t *d_out, hipStream_t s) {
+  BIVX_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t), s));
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_max_u8, dim3(grid_for(n, kThreads * 16, 2048)), dim3(kThreads), 0, s, d_in, n, d_out);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_make_vchrom(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t ntypes, uint32_t *d_vchrom,
+                       hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_make_vchrom, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_chrom, d_type, n, ntypes,
+                     d_vchrom);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gather_u8(const uint8_t *d_src, const uint32_t *d_ids, size_t n, size_t n_src, uint8_t *d_out,
+                     hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_gather_u8, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_src, d_ids, n, n_src, d_out);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

@@ -38,6 +38,8 @@ struct bivx_index {
   hipStream_t stream = nullptr;
   // append-order copy (what RbTree::insert_node received, in order)
   uint32_t *d_chrom = nullptr, *d_low = nullptr, *d_high = nullptr;
+  uint8_t *d_type = nullptr;  // svtype per interval (bivx_append_typed); allocated with the first typed append
+  bool typed = false;         // some append carried types
   size_t n = 0, cap = 0;
   // built index
   bool built = false;
@@ -46,8 +48,9 @@ struct bivx_index {
   uint32_t *d_id = nullptr;
   uint32_t *d_table = nullptr;
   SegDesc *d_seg = nullptr;
-  uint32_t *d_chrom_seg = nullptr;
-  uint32_t nchrom = 0, nseg = 0, max_segs = 0;
+  uint2 *d_chrom_rng = nullptr;        // ntypes rows of nchrom (first segment, count) pairs; row 0 = every type
+  uint32_t nchrom = 0, nseg = 0, ntypes = 1;
+  std::vector<uint32_t> max_segs;      // per row: most segments any one chromosome has
   uint64_t nentries = 0;
   size_t built_n = 0;
   double build_ms = 0.0;
@@ -163,14 +166,16 @@ void free_built(bivx_index *idx) {
   (void)hipFree(idx->d_id);
   (void)hipFree(idx->d_table);
   (void)hipFree(idx->d_seg);
-  (void)hipFree(idx->d_chrom_seg);
+  (void)hipFree(idx->d_chrom_rng);
   idx->d_se = nullptr;
   idx->d_rec = nullptr;
   idx->d_id = nullptr;
   idx->d_table = nullptr;
   idx->d_seg = nullptr;
-  idx->d_chrom_seg = nullptr;
-  idx->nchrom = idx->nseg = idx->max_segs = 0;
+  idx->d_chrom_rng = nullptr;
+  idx->nchrom = idx->nseg = 0;
+  idx->ntypes = 1;
+  idx->max_segs.clear();
   idx->nentries = 0;
   idx->built = false;
 }
@@ -185,10 +190,13 @@ int ensure_capacity(bivx_index *idx, size_t need) {
   if (nc < need) nc = need;
   if (nc > 0xFFFFFFFEull) nc = 0xFFFFFFFEull;
   uint32_t *c = nullptr, *l = nullptr, *h = nullptr;
+  uint8_t *ty = nullptr;
   auto grow = [&]() -> int {
     BIVX_HIP(hipMalloc((void **)&c, nc * sizeof(uint32_t)));
     BIVX_HIP(hipMalloc((void **)&l, nc * sizeof(uint32_t)));
     BIVX_HIP(hipMalloc((void **)&h, nc * sizeof(uint32_t)));
+    BIVX_HIP(hipMalloc((void **)&ty, nc));
+    BIVX_HIP(hipMemsetAsync(ty, 0, nc, idx->stream));
     if (idx->n) {
       // Earlier bivx_append_dev calls copy on the CALLER's streams, which idx->stream is not ordered after: wait
       // for the whole device before the old arrays are read and freed (growth doubles, so this is rare).
@@ -196,16 +204,20 @@ int ensure_capacity(bivx_index *idx, size_t need) {
       BIVX_HIP(hipMemcpyAsync(c, idx->d_chrom, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
       BIVX_HIP(hipMemcpyAsync(l, idx->d_low, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
       BIVX_HIP(hipMemcpyAsync(h, idx->d_high, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
-      BIVX_HIP(hipStreamSynchronize(idx->stream));
+      BIVX_HIP(hipMemcpyAsync(ty, idx->d_type, idx->n, hipMemcpyDeviceToDevice, idx->stream));
     }
+    BIVX_HIP(hipStreamSynchronize(idx->stream));
     return 0;
   };
   if (int rc = grow()) {
     (void)hipFree(c);
     (void)hipFree(l);
     (void)hipFree(h);
+    (void)hipFree(ty);
     return rc;
   }
+  (void)hipFree(idx->d_type);
+  idx->d_type = ty;
   (void)hipFree(idx->d_chrom);
   (void)hipFree(idx->d_low);
   (void)hipFree(idx->d_high);
@@ -216,8 +228,8 @@ int ensure_capacity(bivx_index *idx, size_t need) {
   return 0;
 }
 
-int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high, size_t n,
-                hipMemcpyKind kind, hipStream_t s) {
+int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
+                const uint8_t *svtype, size_t n, hipMemcpyKind kind, hipStream_t s) {
   if (!idx || (n && (!low || !high))) {
     set_error("bivx_append: null argument");
     return BIVX_E_INVALID;
@@ -231,6 +243,12 @@ int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, con
     BIVX_HIP(hipMemsetAsync(idx->d_chrom + idx->n, 0, n * 4, s));
   BIVX_HIP(hipMemcpyAsync(idx->d_low + idx->n, low, n * 4, kind, s));
   BIVX_HIP(hipMemcpyAsync(idx->d_high + idx->n, high, n * 4, kind, s));
+  if (svtype) {
+    BIVX_HIP(hipMemcpyAsync(idx->d_type + idx->n, svtype, n, kind, s));
+    idx->typed = true;
+  } else if (idx->typed) {  // (a fresh allocation is zero already; slots reused after bivx_clear are not)
+    BIVX_HIP(hipMemsetAsync(idx->d_type + idx->n, 0, n, s));
+  }
   if (kind == hipMemcpyHostToDevice) BIVX_HIP(hipStreamSynchronize(s));  // caller may reuse its buffers
   idx->n += n;
   idx->built = false;
@@ -343,17 +361,19 @@ int bits_for(uint32_t maxval) {
   return b;
 }
 
-IndexView view_of(const bivx_index *idx) {
+IndexView view_of(const bivx_index *idx, uint32_t svtype = 0) {
   IndexView v;
   v.se = idx->d_se;
   v.rec = idx->d_rec;
   v.id = idx->d_id;
   v.table = idx->d_table;
   v.seg = idx->d_seg;
-  v.chrom_seg = idx->d_chrom_seg;
+  // row of the requested interval type; a type the index does not hold selects an all-empty row
+  const uint32_t row = svtype < idx->ntypes ? svtype : idx->ntypes;
+  v.chrom_rng = idx->d_chrom_rng + (size_t)row * idx->nchrom;
   v.nchrom = idx->nchrom;
   v.nseg = idx->nseg;
-  v.max_segs = idx->max_segs;
+  v.max_segs = row < idx->max_segs.size() ? idx->max_segs[row] : 0;
   v.flt_kind = BIVX_FILTER_NONE;
   v.flt_dist = 0;
   v.flt_strand = 0;
@@ -385,7 +405,11 @@ int report_device_errors(const bivx_index *idx, const char *who) {
 
 // view with a fused post-filter; the aux pointers are DEVICE pointers here
 int view_with_filter(const bivx_index *idx, const bivx_filter *f, IndexView &v) {
-  v = view_of(idx);
+  if (f && f->svtype > 255u) {
+    set_error("filter svtype %u out of range (0 = any, 1..255)", f->svtype);
+    return BIVX_E_INVALID;
+  }
+  v = view_of(idx, f ? f->svtype : 0u);
   if (!f || f->kind == BIVX_FILTER_NONE) return 0;
   if (f->kind > BIVX_FILTER_SV2NL_TRA) {
     set_error("unknown filter kind %u", f->kind);
@@ -481,6 +505,7 @@ void bivx_destroy(bivx_index *idx) {
   (void)hipFree(idx->d_chrom);
   (void)hipFree(idx->d_low);
   (void)hipFree(idx->d_high);
+  (void)hipFree(idx->d_type);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
   delete idx;
 }
@@ -488,12 +513,23 @@ void bivx_destroy(bivx_index *idx) {
 int bivx_device(const bivx_index *idx) { return idx ? idx->device : -1; }
 
 int bivx_append(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high, size_t n) {
-  return append_impl(idx, chrom, low, high, n, hipMemcpyHostToDevice, idx ? idx->stream : nullptr);
+  return append_impl(idx, chrom, low, high, nullptr, n, hipMemcpyHostToDevice, idx ? idx->stream : nullptr);
+}
+
+int bivx_append_typed(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
+                      const uint8_t *svtype, size_t n) {
+  return append_impl(idx, chrom, low, high, svtype, n, hipMemcpyHostToDevice, idx ? idx->stream : nullptr);
 }
 
 int bivx_append_dev(bivx_index *idx, const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
                     size_t n, void *stream) {
-  return append_impl(idx, d_chrom, d_low, d_high, n, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+  return append_impl(idx, d_chrom, d_low, d_high, nullptr, n, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+}
+
+int bivx_append_typed_dev(bivx_index *idx, const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
+                          const uint8_t *d_svtype, size_t n, void *stream) {
+  return append_impl(idx, d_chrom, d_low, d_high, d_svtype, n, hipMemcpyDeviceToDevice,
+                     static_cast<hipStream_t>(stream));
 }
 
 int bivx_clear(bivx_index *idx) {
@@ -505,6 +541,7 @@ int bivx_clear(bivx_index *idx) {
   BIVX_HIP(hipStreamSynchronize(idx->stream));
   free_built(idx);
   idx->n = 0;
+  idx->typed = false;
   return 0;
 }
 
@@ -541,23 +578,60 @@ int bivx_build(bivx_index *idx) {
     return BIVX_E_RANGE;
   }
   const uint32_t nchrom = n ? max_chrom + 1 : 0;
+  // 1b. interval types (bivx_append_typed): the index is partitioned by (chromosome, svtype) — a "virtual
+  // chromosome" id chrom * ntypes + svtype takes the chromosome's place in everything below, so a query that asks
+  // for one type walks only that type's segments and pays nothing per candidate (the svtype filter of
+  // mapper.hpp:153-156, done by the layout instead of by three trees)
+  uint32_t ntypes = 1;
+  const uint32_t *d_part = idx->d_chrom;  // what partitions the index
+  if (n && idx->typed) {
+    uint32_t max_type = 0;
+    BIVX_TRY(launch_max_u8(idx->d_type, n, d_scalar, s));
+    BIVX_HIP(hipMemcpyAsync(&max_type, d_scalar, 4, hipMemcpyDeviceToHost, s));
+    BIVX_HIP(hipStreamSynchronize(s));
+    ntypes = max_type + 1;
+    if (ntypes > 1) {
+      if ((uint64_t)nchrom * ntypes > BIVX_MAX_CHROMS) {
+        set_error("%u chromosome ids x %u interval types exceed BIVX_MAX_CHROMS", nchrom, ntypes);
+        return BIVX_E_RANGE;
+      }
+      uint32_t *d_v = nullptr;
+      BIVX_TRY(tmp.alloc(&d_v, n));
+      BIVX_TRY(launch_make_vchrom(idx->d_chrom, idx->d_type, n, ntypes, d_v, s));
+      d_part = d_v;
+    }
+  }
+  const uint32_t nvchrom = nchrom * ntypes;
 
   // 2. per (chromosome, length bin) statistics -> host
-  std::vector<BinStats> st((size_t)nchrom * kLenBins);
+  std::vector<BinStats> st((size_t)nvchrom * kLenBins);
   ClassPlan plan;
   if (n) {
     BinStats *d_stats = nullptr;
     BIVX_TRY(tmp.alloc(&d_stats, st.size()));
-    BIVX_TRY(launch_bin_stats(idx->d_chrom, idx->d_low, idx->d_high, n, nchrom, d_stats, s));
+    BIVX_TRY(launch_bin_stats(d_part, idx->d_low, idx->d_high, n, nvchrom, d_stats, s));
     BIVX_HIP(hipMemcpyAsync(st.data(), d_stats, st.size() * sizeof(BinStats), hipMemcpyDeviceToHost, s));
     BIVX_HIP(hipStreamSynchronize(s));
   }
   // 3. length classes, segment descriptors
-  BIVX_TRY(plan_classes(st, nchrom, plan));
+  BIVX_TRY(plan_classes(st, nvchrom, plan));
   const uint32_t nseg = (uint32_t)plan.segs.size();
 
-  BIVX_HIP(hipMalloc((void **)&idx->d_chrom_seg, (size_t)(nchrom + 1) * 4));
-  BIVX_HIP(hipMemcpyAsync(idx->d_chrom_seg, plan.chrom_seg.data(), (size_t)(nchrom + 1) * 4, hipMemcpyHostToDevice, s));
+  // segment ranges per chromosome, one row per interval type: row 0 = every type (the types of a chromosome are
+  // neighbours in the segment order), row t = type t, and one all-empty row behind them for types the index lacks
+  std::vector<uint2> rng((size_t)(ntypes + 1) * (nchrom ? nchrom : 1), make_uint2(0u, 0u));
+  std::vector<uint32_t> max_segs(ntypes + 1, 0u);
+  for (uint32_t c = 0; c < nchrom; ++c) {
+    const uint32_t *cs = plan.chrom_seg.data() + (size_t)c * ntypes;
+    rng[c] = make_uint2(cs[0], cs[ntypes] - cs[0]);
+    max_segs[0] = std::max(max_segs[0], cs[ntypes] - cs[0]);
+    for (uint32_t t = 1; t < ntypes; ++t) {
+      rng[(size_t)t * nchrom + c] = make_uint2(cs[t], cs[t + 1] - cs[t]);
+      max_segs[t] = std::max(max_segs[t], cs[t + 1] - cs[t]);
+    }
+  }
+  BIVX_HIP(hipMalloc((void **)&idx->d_chrom_rng, rng.size() * sizeof(uint2)));
+  BIVX_HIP(hipMemcpyAsync(idx->d_chrom_rng, rng.data(), rng.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
   BIVX_HIP(hipMalloc((void **)&idx->d_seg, (size_t)(nseg ? nseg : 1) * sizeof(SegDesc)));
   if (nseg)
     BIVX_HIP(hipMemcpyAsync(idx->d_seg, plan.segs.data(), (size_t)nseg * sizeof(SegDesc), hipMemcpyHostToDevice, s));
@@ -578,7 +652,7 @@ int bivx_build(bivx_index *idx) {
       d_rscr = p;
     }
     BIVX_HIP(hipMemcpyAsync(d_bin2seg, plan.bin2seg.data(), plan.bin2seg.size() * 4, hipMemcpyHostToDevice, s));
-    BIVX_TRY(launch_make_segkeys(idx->d_chrom, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey, vA, s));
+    BIVX_TRY(launch_make_segkeys(d_part, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey, vA, s));
     BIVX_HIP(hipMemcpyAsync(kA, idx->d_low, n * 4, hipMemcpyDeviceToDevice, s));
     // 5. stable sort by low, then by segment (LSD): final order (segment, low, id)
     BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), d_rscr, s));
@@ -607,9 +681,8 @@ int bivx_build(bivx_index *idx) {
   BIVX_HIP(hipStreamSynchronize(s));
   idx->nchrom = nchrom;
   idx->nseg = nseg;
-  idx->max_segs = 0;
-  for (uint32_t c = 0; c < nchrom; ++c)
-    idx->max_segs = std::max(idx->max_segs, plan.chrom_seg[c + 1] - plan.chrom_seg[c]);
+  idx->ntypes = ntypes;
+  idx->max_segs = std::move(max_segs);
   idx->nentries = plan.nentries;
   idx->built = true;
   idx->built_n = n;
@@ -620,6 +693,27 @@ int bivx_build(bivx_index *idx) {
 int bivx_is_built(const bivx_index *idx) { return idx && idx->built && idx->built_n == idx->n; }
 size_t bivx_size(const bivx_index *idx) { return idx ? idx->n : 0; }
 uint32_t bivx_num_chroms(const bivx_index *idx) { return idx ? idx->nchrom : 0; }
+uint32_t bivx_num_types(const bivx_index *idx) { return idx ? idx->ntypes : 0; }
+
+int bivx_get_svtypes(const bivx_index *idx, const uint32_t *ids, size_t n, uint8_t *svtype_out) {
+  if (!idx || (n && (!ids || !svtype_out))) {
+    set_error("bivx_get_svtypes: null argument");
+    return BIVX_E_INVALID;
+  }
+  if (n == 0) return 0;
+  BIVX_GUARD(idx);
+  hipStream_t s = idx->stream;
+  TempPool tmp(idx);
+  uint32_t *d_ids = nullptr;
+  uint8_t *d_t = nullptr;
+  BIVX_TRY(tmp.alloc(&d_ids, n));
+  BIVX_TRY(tmp.alloc(&d_t, n));
+  BIVX_HIP(hipMemcpyAsync(d_ids, ids, n * 4, hipMemcpyHostToDevice, s));
+  BIVX_TRY(launch_gather_u8(idx->typed ? idx->d_type : nullptr, d_ids, n, idx->n, d_t, s));
+  BIVX_HIP(hipMemcpyAsync(svtype_out, d_t, n, hipMemcpyDeviceToHost, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  return 0;
+}
 
 int bivx_get_intervals(const bivx_index *idx, const uint32_t *ids, size_t n, uint32_t *chrom_out, uint32_t *low_out,
                        uint32_t *high_out) {
@@ -845,7 +939,8 @@ namespace {
 constexpr size_t kSmallBatch = 2048, kSmallBatchIds = 32;
 constexpr int kSmallBatchOverflow = 1;
 int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
-                        size_t q, int sort_by_id, uint64_t *offsets_out, uint32_t **hit_ids_out) {
+                        size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+                        uint32_t **hit_ids_out) {
   hipStream_t s = idx->stream;
   const size_t nq_words = (qchrom ? 3 : 2) * q;
   const size_t cap = kSmallBatchIds * q + 1024;
@@ -861,7 +956,8 @@ int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uin
   BIVX_HIP(hipMemcpyAsync(d_buf, h.data(), nq_words * 4, hipMemcpyHostToDevice, s));
   uint64_t *d_off = reinterpret_cast<uint64_t *>(d_buf + q_words);
   uint32_t *d_hits = d_buf + q_words + off_words;
-  BIVX_TRY(bivx_query_dev_s(idx, qchrom ? d_buf + 2 * q : nullptr, d_buf, d_buf + q, q, nullptr, sort_by_id, d_off,
+  // (the filter can only be a type selection here: kind NONE, no aux arrays to upload)
+  BIVX_TRY(bivx_query_dev_s(idx, qchrom ? d_buf + 2 * q : nullptr, d_buf, d_buf + q, q, filter, sort_by_id, d_off,
                             d_hits, cap, nullptr, 0, s));
   // offsets and the first ids in one copy: few queries rarely have more, and then a second copy fetches all
   const size_t have = std::min(cap, 4 * q + 128);
@@ -892,7 +988,9 @@ int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uin
 // uploads a host-side filter's aux arrays; `dev` receives the same filter with device pointers
 int upload_filter(TempPool &tmp, const bivx_index *idx, const bivx_filter *f, size_t q, hipStream_t s, bivx_filter &dev) {
   dev = bivx_filter{};
-  if (!f || f->kind == BIVX_FILTER_NONE) return 0;
+  if (!f) return 0;
+  dev.svtype = f->svtype;  // a type selection travels with every kind, NONE included
+  if (f->kind == BIVX_FILTER_NONE) return 0;
   dev = *f;
   dev.query_aux = dev.interval_aux = nullptr;
   if (f->query_aux && q) {
@@ -995,7 +1093,7 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
   if (q <= kSmallBatch && (!filter || filter->kind == BIVX_FILTER_NONE)) {
-    int rc = find_overlaps_small(idx, qchrom, qlow, qhigh, q, sort_by_id, offsets_out, hit_ids_out);
+    int rc = find_overlaps_small(idx, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
     if (rc != kSmallBatchOverflow) return rc;
   }
   TempPool tmp(idx);

@@ -52,10 +52,12 @@ struct IndexView {
   const uint32_t *id;         // append-order id of each sorted slot
   const uint32_t *table;      // bucket directories, all segments back to back
   const SegDesc *seg;         // nseg descriptors, grouped by chromosome
-  const uint32_t *chrom_seg;  // nchrom + 1: segments of chromosome c are [chrom_seg[c], chrom_seg[c+1])
+  // segments of chromosome c as (first, count), for the interval type this call asks for: the index keeps one such
+  // row per svtype (row 0: every type), so selecting a type costs the kernels nothing (bivx_filter::svtype)
+  const uint2 *chrom_rng;
   uint32_t nchrom;
   uint32_t nseg;
-  uint32_t max_segs;          // most segments any one chromosome has
+  uint32_t max_segs;          // most segments any one chromosome has (for the selected type)
   // optional post-filter fused into the enumeration (bivx_filter): a candidate must pass it as well
   uint32_t flt_kind;          // BIVX_FILTER_*
   uint32_t flt_dist;
@@ -88,6 +90,13 @@ int exclusive_scan_u32_u32(const uint32_t *d_in, uint32_t *d_out, size_t n, void
 int launch_bin_stats(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n,
                      uint32_t nchrom, BinStats *d_stats, hipStream_t s);
 int launch_max_u32(const uint32_t *d_in, size_t n, uint32_t *d_out, hipStream_t s);
+int launch_max_u8(const uint8_t *d_in, size_t n, uint32_t *d_out, hipStream_t s);
+// vchrom[i] = chrom[i] * ntypes + svtype[i] (chrom may be nullptr: all 0)
+int launch_make_vchrom(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t ntypes, uint32_t *d_vchrom,
+                       hipStream_t s);
+// out[i] = src ? src[ids[i]] : 0 for ids[i] < n_src, else 0xFF
+int launch_gather_u8(const uint8_t *d_src, const uint32_t *d_ids, size_t n, size_t n_src, uint8_t *d_out,
+                     hipStream_t s);
 int launch_make_segkeys(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n,
                         const uint32_t *d_bin2seg, uint32_t *d_segkey, uint32_t *d_ids, hipStream_t s);
 // stable LSD radix sort of (key, val) pairs on key bits [0, nbits); result ends in (*keys, *vals)

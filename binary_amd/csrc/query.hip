@@ -30,9 +30,9 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
                                                      const uint64_t *__restrict__ offsets,
                                                      uint32_t *__restrict__ out) {
   __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
-  __shared__ uint32_t s_cs[LDS_DESC ? kLdsChroms + 1 : 1];
+  __shared__ uint2 s_cs[LDS_DESC ? kLdsChroms : 1];
   const SegDesc *segs;
-  const uint32_t *cs;
+  const uint2 *cs;
   stage_descriptors<LDS_DESC>(v, s_seg, s_cs, segs, cs);
   if (LDS_DESC) __syncthreads();
   const size_t q = (size_t)blockIdx.x * kQThreads + threadIdx.x;

@@ -20,7 +20,7 @@ constexpr uint32_t kRows = 4;        // rows of 64 slots (and their ids) the wav
 constexpr uint32_t kSlabSlots = 256;  // candidate slots a wavefront stages through LDS when its 64 windows are neighbours
 constexpr uint32_t kSlabMinLanes = 32;  // ... and at least this many of its lanes' windows fit the slab
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
-constexpr uint32_t kLdsChroms = 511; // ... with chrom_seg (2 KiB); larger indexes read them from global
+constexpr uint32_t kLdsChroms = 512; // ... with the chromosomes' segment ranges (4 KiB); larger indexes read them from global
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -473,25 +473,25 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
   return acc;
 }
 
-// Stages chrom_seg and the descriptors through LDS (block-cooperative); returns the pointers to use.
+// Stages the chromosomes' segment ranges and the descriptors through LDS (block-cooperative); returns the pointers to use.
 template <bool LDS_DESC>
-__device__ __forceinline__ void stage_descriptors(const IndexView &v, SegDesc *s_seg, uint32_t *s_cs,
-                                                  const SegDesc *&segs, const uint32_t *&cs) {
+__device__ __forceinline__ void stage_descriptors(const IndexView &v, SegDesc *s_seg, uint2 *s_cs,
+                                                  const SegDesc *&segs, const uint2 *&cs) {
   if (LDS_DESC) {
     const uint4 *src = reinterpret_cast<const uint4 *>(v.seg);
     uint4 *dst = reinterpret_cast<uint4 *>(s_seg);
     for (uint32_t t = threadIdx.x; t < v.nseg * 2; t += blockDim.x) dst[t] = src[t];
-    for (uint32_t t = threadIdx.x; t <= v.nchrom; t += blockDim.x) s_cs[t] = v.chrom_seg[t];
+    for (uint32_t t = threadIdx.x; t < v.nchrom; t += blockDim.x) s_cs[t] = v.chrom_rng[t];
     segs = s_seg;
     cs = s_cs;
   } else {
     segs = v.seg;
-    cs = v.chrom_seg;
+    cs = v.chrom_rng;
   }
 }
 
 template <bool F>
-__device__ __forceinline__ Query load_query(const IndexView &v, const uint32_t *cs, const uint32_t *qchrom,
+__device__ __forceinline__ Query load_query(const IndexView &v, const uint2 *cs, const uint32_t *qchrom,
                                             const uint32_t *qlow, const uint32_t *qhigh, size_t q, bool valid) {
   Query qy{0u, 0u, 0u, 0u, 0u};
   if (valid) {
@@ -500,8 +500,9 @@ __device__ __forceinline__ Query load_query(const IndexView &v, const uint32_t *
     if (F && v.flt_qaux) qy.aux = v.flt_qaux[q];
     const uint32_t c = qchrom ? qchrom[q] : 0u;
     if (c < v.nchrom) {
-      qy.s0 = cs[c];
-      qy.nseg = cs[c + 1] - qy.s0;
+      const uint2 r = cs[c];
+      qy.s0 = r.x;
+      qy.nseg = r.y;
     }
   }
   return qy;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
                                                            uint64_t *__restrict__ total_out, uint32_t seq) {
   const bool self_clean = (flags & kFlagSelfClean) != 0;
   __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
-  __shared__ uint32_t s_cs[LDS_DESC ? kLdsChroms + 1 : 1];
+  __shared__ uint2 s_cs[LDS_DESC ? kLdsChroms : 1];
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_last;  // this tile finished its prefix sweep last: it zeroes the workspace for the next call
   __shared__ uint32_t s_wsum[kFWaves];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
   if (threadIdx.x == 0)
     s_tile = U ? blockIdx.x : atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTicket), 1u);
   const SegDesc *segs;
-  const uint32_t *cs;
+  const uint2 *cs;
   stage_descriptors<LDS_DESC>(v, s_seg, s_cs, segs, cs);
   __syncthreads();
   const uint32_t tile = s_tile;

@@ -69,8 +69,10 @@ class IntervalIndex:
         self.close()
 
     # ---- build side (RbTree::insert_node, rb_tree.hpp:111-117,145-149) ---------------------------------
-    def insert_node(self, low, high, chrom=None) -> None:
-        """Append intervals [low[i], high[i]] (closed); ids continue in append order."""
+    def insert_node(self, low, high, chrom=None, svtype=None) -> None:
+        """Append intervals [low[i], high[i]] (closed); ids continue in append order. svtype (uint8, 1..255) labels
+        the intervals (the svtype column of the VCF-record intervals, vcf.hpp:598-639): queries may then ask for one
+        type (svtype= of the query methods) and meet only those."""
         if torch is not None and isinstance(low, torch.Tensor) and low.is_cuda:
             n = low.numel()
             _check_dev_tensor(low, "low")
@@ -78,7 +80,12 @@ class IntervalIndex:
             if chrom is not None:
                 _check_dev_tensor(chrom, "chrom", n)
             s = torch.cuda.current_stream(low.device).cuda_stream
-            capi.check(self._L.bivx_append_dev(self._h, _tptr(chrom), _tptr(low), _tptr(high), n, C.c_void_p(s)))
+            if svtype is not None:
+                _check_dev_tensor(svtype, "svtype", n, 1)
+                capi.check(self._L.bivx_append_typed_dev(self._h, _tptr(chrom), _tptr(low), _tptr(high), _tptr(svtype),
+                                                         n, C.c_void_p(s)))
+            else:
+                capi.check(self._L.bivx_append_dev(self._h, _tptr(chrom), _tptr(low), _tptr(high), n, C.c_void_p(s)))
             torch.cuda.current_stream(low.device).synchronize()  # the copy reads caller memory
             return
         low, high = _u32(low).ravel(), _u32(high).ravel()
@@ -87,7 +94,13 @@ class IntervalIndex:
         c = None if chrom is None else _u32(chrom).ravel()
         if c is not None and c.shape != low.shape:
             raise ValueError("chrom must have the same length as low")
-        capi.check(self._L.bivx_append(self._h, _ptr(c), _ptr(low), _ptr(high), low.size))
+        if svtype is not None:
+            t = np.ascontiguousarray(svtype, dtype=np.uint8).ravel()
+            if t.shape != low.shape:
+                raise ValueError("svtype must have the same length as low")
+            capi.check(self._L.bivx_append_typed(self._h, _ptr(c), _ptr(low), _ptr(high), _ptr(t), low.size))
+        else:
+            capi.check(self._L.bivx_append(self._h, _ptr(c), _ptr(low), _ptr(high), low.size))
 
     def build(self) -> None:
         """Makes the appended set searchable (the reference does this incrementally per insert)."""
@@ -104,6 +117,20 @@ class IntervalIndex:
 
     def num_chroms(self) -> int:
         return int(self._L.bivx_num_chroms(self._h))
+
+    def num_types(self) -> int:
+        return int(self._L.bivx_num_types(self._h))
+
+    def get_svtypes(self, ids) -> np.ndarray:
+        ids = _u32(ids).ravel()
+        out = np.empty(ids.size, np.uint8)
+        capi.check(self._L.bivx_get_svtypes(self._h, _ptr(ids), ids.size, _ptr(out)))
+        return out
+
+    @staticmethod
+    def type_filter(svtype: int):
+        """bivx_filter that only selects the intervals of one svtype (no post-filter)."""
+        return capi.Filter(capi.FILTER_NONE, 0, 0, int(svtype), None, None)
 
     def stats(self) -> dict:
         st = capi.Stats()
@@ -128,8 +155,8 @@ class IntervalIndex:
             self.build()
 
     # ---- query side, host arrays (IntervalTree::find_overlaps interval_tree.hpp:161-168,306-334) -------
-    def find_overlaps(self, qlow, qhigh, qchrom=None, sort_by_id: bool = True):
-        """CSR of all overlaps: (offsets uint64[q+1], hit_ids uint32[H])."""
+    def find_overlaps(self, qlow, qhigh, qchrom=None, sort_by_id: bool = True, svtype: int = 0):
+        """CSR of all overlaps: (offsets uint64[q+1], hit_ids uint32[H]). svtype != 0: only intervals of that type."""
         self._ensure_built()
         qlow, qhigh = _u32(qlow).ravel(), _u32(qhigh).ravel()
         if qlow.shape != qhigh.shape:
@@ -138,7 +165,9 @@ class IntervalIndex:
         q = qlow.size
         offsets = np.zeros(q + 1, dtype=np.uint64)
         hp = C.POINTER(C.c_uint32)()
-        capi.check(self._L.bivx_find_overlaps(self._h, _ptr(qc), _ptr(qlow), _ptr(qhigh), q, None,
+        flt = self.type_filter(svtype) if svtype else None
+        capi.check(self._L.bivx_find_overlaps(self._h, _ptr(qc), _ptr(qlow), _ptr(qhigh), q,
+                                              None if flt is None else C.byref(flt),
                                               1 if sort_by_id else 0, _ptr(offsets), C.byref(hp)))
         total = int(offsets[-1])
         if total == 0:
@@ -192,12 +221,13 @@ class IntervalIndex:
         return int(self._L.bivx_query_workspace_bytes(int(q)))
 
     @staticmethod
-    def device_filter(kind: int, max_dist: int, use_strand: bool = True, query_aux=None, interval_aux=None):
+    def device_filter(kind: int, max_dist: int, use_strand: bool = True, query_aux=None, interval_aux=None,
+                      svtype: int = 0):
         """bivx_filter over DEVICE tensors (fused sv2nl check_condition, include/bivx.h). Keep the tensors alive."""
         for name, t in (("query_aux", query_aux), ("interval_aux", interval_aux)):
             if t is not None:
                 _check_dev_tensor(t, name)
-        return capi.Filter(kind, max_dist, 1 if use_strand else 0, 0,
+        return capi.Filter(kind, max_dist, 1 if use_strand else 0, int(svtype),
                            None if query_aux is None else query_aux.data_ptr(),
                            None if interval_aux is None else interval_aux.data_ptr())
 

@@ -3,11 +3,13 @@
 // Same command line, defaults, validation, output files and line format as the reference
 // (standalone/sv2nl/source/main.cpp:83-165, run() :46-81), same mapping rules
 // (include/mapper.hpp:147-246, source/mapper.cpp:50-170, include/helper.hpp:16-91, source/writer.cpp:21-28).
-// What changed is the engine: instead of one red-black interval tree per chromosome task, each mapper appends
-// its SV records to ONE device index (chromosome id per record), asks all its NL records in one batch through
-// the C ABI (include/bivx.h), and the mapper's check_condition runs on the device, fused into the overlap
-// enumeration (bivx_filter). The reference's per-chromosome thread pool (-t) has nothing left to do; the
-// flag is parsed and validated for compatibility.
+// What changed is the engine: instead of one red-black interval tree per (mapper, chromosome) task, ALL SV records
+// go into ONE device index as (chromosome id, start, end, svtype) columns (bivx_append_typed: DUP = 1, INV = 2,
+// BND = 3; the index is partitioned by chromosome and type, so the svtype filter of mapper.hpp:153-156 costs
+// nothing per candidate), each mapper asks all its NL records in one batch through the C ABI (include/bivx.h) with
+// its type selected, and the mapper's check_condition runs on the device, fused into the overlap enumeration
+// (bivx_filter). --index-per-mapper keeps round 1's three separate indexes for A/B. The reference's per-chromosome
+// thread pool (-t) has nothing left to do; the flag is parsed and validated for compatibility.
 //
 // Output line ORDER: the reference's tasks append concurrently under a mutex (writer.hpp:33-38), so its order is
 // not deterministic; here lines come out in NL-contig order, NL file order, SV file order.
@@ -98,26 +100,84 @@ namespace sv2nl {
     std::string sv_path, nl_path, output{"output.tsv"};
     std::uint32_t dis{1000000};
     int threads{NUM_THREADS};
-    bool short_reads{false}, merge{false}, debug{false}, host_filter{false};
+    bool short_reads{false}, merge{false}, debug{false}, host_filter{false}, index_per_mapper{false};
     int device{0};
   };
+
+  enum class Kind { Dup, Inv, Tra };
+  inline auto type_code(Kind k) -> std::uint8_t { return k == Kind::Dup ? 1 : k == Kind::Inv ? 2 : 3; }
+
+  // The tree side of all three mappers in ONE device index. DUP / INV records enter validated under their chromosome
+  // (mapper.hpp:153-156); BND records enter as read, all under chromosome 0 (TraMapper builds one tree of every
+  // chromosome's records, un-validated, mapper.cpp:158-170); the svtype column keeps the three apart.
+  struct SharedIndex {
+    bivx_index *ix = nullptr;
+    std::vector<Record> items;             // stored record of each interval id
+    std::vector<std::uint32_t> iaux;       // TRA: ordered chromosome pair << 1 | swapped (0 for DUP / INV)
+    std::unordered_map<std::string, std::uint32_t> chrom_id;
+    std::map<std::pair<std::string, std::string>, std::uint32_t> pair_id;
+    ~SharedIndex() {
+      if (ix) bivx_destroy(ix);
+    }
+  };
+
+  inline void die_bivx(const char *what);
+
+  inline void build_shared(SharedIndex &sh, const std::vector<Record> &sv, const Options &opt) {
+    std::vector<std::uint32_t> ic, ilo, ihi;
+    std::vector<std::uint8_t> ity;
+    auto id_of = [&](const std::string &c) {
+      auto it = sh.chrom_id.find(c);
+      if (it != sh.chrom_id.end()) return it->second;
+      auto v = static_cast<std::uint32_t>(sh.chrom_id.size());
+      sh.chrom_id.emplace(c, v);
+      return v;
+    };
+    for (auto const &r : sv) {
+      Kind k;
+      if (r.svtype == "DUP") k = Kind::Dup;
+      else if (r.svtype == "INV") k = Kind::Inv;
+      else if (r.svtype == "BND") k = Kind::Tra;
+      else continue;
+      Record s = k == Kind::Tra ? r : validate_record(r);
+      ic.push_back(k == Kind::Tra ? 0u : id_of(s.chrom));
+      ilo.push_back(s.pos);
+      ihi.push_back(s.svend);
+      ity.push_back(type_code(k));
+      if (k == Kind::Tra) {
+        auto t = two_chroms_with_pos(s);
+        auto key = std::make_pair(t.c1, t.c2);
+        auto it = sh.pair_id.find(key);
+        if (it == sh.pair_id.end()) it = sh.pair_id.emplace(key, static_cast<std::uint32_t>(sh.pair_id.size())).first;
+        sh.iaux.push_back((it->second << 1) | (t.swapped ? 1u : 0u));
+      } else {
+        sh.iaux.push_back(0u);
+      }
+      sh.items.push_back(std::move(s));
+    }
+    if (sh.items.empty()) return;
+    if (bivx_create(&sh.ix, opt.device) != 0) die_bivx("bivx_create");
+    if (bivx_append_typed(sh.ix, ic.data(), ilo.data(), ihi.data(), ity.data(), sh.items.size()) != 0)
+      die_bivx("bivx_append_typed");
+    if (bivx_build(sh.ix) != 0) die_bivx("bivx_build");
+  }
 
   inline void die_bivx(const char *what) {
     std::fprintf(stderr, "[sv2nl] %s: %s\n", what, bivx_last_error());
     std::exit(2);
   }
 
-  enum class Kind { Dup, Inv, Tra };
-
-  // One mapper = one device index + one batch of queries.
+  // One mapper = one batch of queries against its type's partition of the shared index (or, with
+  // --index-per-mapper, against an index of its own).
   class Mapper {
   public:
     Mapper(Kind kind, std::string nl_type, std::string sv_type, const Options &opt)
         : kind_(kind), nl_type_(std::move(nl_type)), sv_type_(std::move(sv_type)), opt_(opt) {}
 
     // sv: all SV records (file order). nl: NL records before the first unreadable one. chroms: NL header contigs.
-    auto map(const std::vector<Record> &sv, const std::vector<Record> &nl, const std::vector<std::string> &chroms)
-        -> std::vector<std::string> {
+    auto map(const std::vector<Record> &sv, const std::vector<Record> &nl, const std::vector<std::string> &chroms,
+             const SharedIndex *shared) -> std::vector<std::string> {
+      if (shared != nullptr) return map_shared(*shared, nl, chroms);
       std::unordered_map<std::string, std::uint32_t> chrom_id;
       auto id_of = [&](const std::string &c) {
         auto it = chrom_id.find(c);
@@ -211,6 +271,67 @@ namespace sv2nl {
         bivx_destroy(ix);
       }
 
+      return emit(qrec, qval, off, hits, items);
+    }
+
+    // the same against the shared typed index: only the query side is assembled here
+    auto map_shared(const SharedIndex &sh, const std::vector<Record> &nl, const std::vector<std::string> &chroms)
+        -> std::vector<std::string> {
+      std::vector<const Record *> qrec;
+      std::vector<Record> qval;
+      std::vector<std::uint32_t> qc, qlo, qhi, qaux;
+      for (auto const &chrom : chroms) {
+        if (chrom.find('_') != std::string::npos) continue;
+        for (auto const &r : nl) {
+          if (r.chrom != chrom || r.svtype != nl_type_) continue;
+          Record q = validate_record(r);
+          std::uint32_t aux = 0, c = 0;
+          if (kind_ == Kind::Tra) {
+            auto t = two_chroms_with_pos(q);
+            auto it = sh.pair_id.find(std::make_pair(t.c1, t.c2));
+            aux = ((it == sh.pair_id.end() ? 0x7FFFFFFFu : it->second) << 1) | (t.swapped ? 1u : 0u);
+          } else {
+            auto it = sh.chrom_id.find(q.chrom);
+            c = it == sh.chrom_id.end() ? 0xFFFFFFFFu : it->second;  // no SV record on this chromosome: empty tree
+            if (kind_ == Kind::Inv) aux = (q.strand1 ? 1u : 0u) | (q.strand2 ? 2u : 0u);
+          }
+          qrec.push_back(&r);
+          qc.push_back(c);
+          qlo.push_back(q.pos);
+          qhi.push_back(q.svend);
+          qaux.push_back(aux);
+          qval.push_back(std::move(q));
+        }
+      }
+      std::vector<std::string> lines;
+      if (qrec.empty()) return lines;
+      std::vector<std::uint64_t> off(qrec.size() + 1, 0);
+      std::vector<std::uint32_t> hits;
+      if (sh.ix != nullptr) {
+        bivx_filter flt{};
+        flt.kind = opt_.host_filter ? BIVX_FILTER_NONE
+                   : kind_ == Kind::Dup ? BIVX_FILTER_SV2NL_DUP
+                   : kind_ == Kind::Inv ? BIVX_FILTER_SV2NL_INV
+                                        : BIVX_FILTER_SV2NL_TRA;
+        flt.max_dist = opt_.dis;
+        flt.use_strand = opt_.short_reads ? 0u : 1u;
+        flt.svtype = type_code(kind_);  // this mapper's partition of the index (mapper.hpp:153-156)
+        flt.query_aux = qaux.data();
+        flt.interval_aux = sh.iaux.data();
+        if (bivx_count_f(sh.ix, qc.data(), qlo.data(), qhi.data(), qrec.size(), &flt, off.data()) != 0)
+          die_bivx("bivx_count_f");
+        hits.resize(static_cast<std::size_t>(off.back()));
+        if (bivx_fill_f(sh.ix, qc.data(), qlo.data(), qhi.data(), qrec.size(), &flt, off.data(), hits.data(), 1) != 0)
+          die_bivx("bivx_fill_f");
+      }
+      return emit(qrec, qval, off, hits, sh.items);
+    }
+
+    // hits -> output lines: the first NL record of each key with a surviving hit wins (mapper.hpp:213,228-232)
+    auto emit(const std::vector<const Record *> &qrec, const std::vector<Record> &qval,
+              const std::vector<std::uint64_t> &off, const std::vector<std::uint32_t> &hits,
+              const std::vector<Record> &items) const -> std::vector<std::string> {
+      std::vector<std::string> lines;
       std::unordered_set<std::string> cache;  // ThreadSafeMap of the reference: keys that already produced output
       for (std::size_t i = 0; i < qrec.size(); ++i) {
         const Record &orig = *qrec[i];
@@ -275,7 +396,8 @@ namespace sv2nl {
            "  -h, --help            Print help\n"
            "  -v, --version         Print the current version number\n"
            "      --device arg      HIP device ordinal (default: 0 or $BIVX_DEVICE)\n"
-           "      --host-filter     Evaluate check_condition on the host instead of on the device\n";
+           "      --host-filter     Evaluate check_condition on the host instead of on the device\n"
+           "      --index-per-mapper  One device index per mapper instead of one typed index for all three\n";
   }
 
 }  // namespace sv2nl
@@ -330,6 +452,8 @@ int main(int argc, char **argv) {
       opt.device = std::stoi(value("device"));
     } else if (a == "--host-filter") {
       opt.host_filter = true;
+    } else if (a == "--index-per-mapper") {
+      opt.index_per_mapper = true;
     } else if (a.size() > 1 && a[0] == '-') {
       std::fprintf(stderr, "[sv2nl] error parsing options: Option '%s' does not exist\n%s\n", a.c_str(), usage().c_str());
       return 1;
@@ -389,8 +513,11 @@ int main(int argc, char **argv) {
       for (auto const &p : parts) write_part(p, {});
       return 1;
     }
+    SharedIndex shared;
+    if (!opt.index_per_mapper) build_shared(shared, sv, opt);
+    const SharedIndex *sh = opt.index_per_mapper ? nullptr : &shared;
     auto run = [&](int part, Kind kind, const char *nl_type, const char *sv_type) {
-      write_part(parts[part], Mapper(kind, nl_type, sv_type, opt).map(sv, nl, chroms));
+      write_part(parts[part], Mapper(kind, nl_type, sv_type, opt).map(sv, nl, chroms, sh));
     };
     if (threaded) {
       auto dup = std::async(std::launch::async, run, 0, Kind::Dup, "TDUP", "DUP");  // main.cpp:52-58

@@ -216,7 +216,20 @@ namespace binary::algorithm::tree {
     [[nodiscard]] auto empty() const -> bool { return items_.empty(); }
 
     // ---- query side (reference interval_tree.hpp:152-168) ------------------------------------------------------
+    /// HitOrder::Insertion (default): exact on existence, returns the overlapping interval inserted first (one device
+    /// call). HitOrder::ReferencePreorder: the reference's own answer — the single root-to-leaf descent of
+    /// interval_tree.hpp:290-304 on the replayed host tree, which returns whichever overlapping node the descent meets
+    /// first; like the reference it goes left iff q.low <= max(left), with max(nullptr) == lowest().
     [[nodiscard]] auto find_overlap(interval_type const &q) const -> std::optional<interval_type> {
+      if (order_ == HitOrder::ReferencePreorder) {
+        Shape &s = shape();
+        for (raw_pointer x = s.root(); x != nullptr;) {
+          if (q.is_overlap(x->interval)) return x->interval;
+          const key_type left_max = x->left != nullptr ? x->leftr()->max : std::numeric_limits<key_type>::lowest();
+          x = q.low <= left_max ? x->leftr() : x->rightr();
+        }
+        return std::nullopt;
+      }
       sync();
       const std::uint32_t lo = detail::to_u32(q.low), hi = detail::to_u32(q.high);
       std::uint32_t first = BIVX_NO_HIT;

@@ -69,6 +69,16 @@ int bivx_append(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, con
 /* same, device pointers, asynchronous on `stream` */
 int bivx_append_dev(bivx_index *idx, const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
                     size_t n, void *stream);
+/* replaces: the (chrom, start, end, svtype) columns of the records that become tree nodes — BaseVcfInterval
+ * (library/include/binary/parser/vcf.hpp:598-639: low = record.pos, high = record.info->svend) filtered by svtype
+ * before insertion (standalone/sv2nl/include/mapper.hpp:153-156). svtype[i] in 1..255 labels interval i (0 = no
+ * type; bivx_append appends type 0). The built index is partitioned by (chromosome, svtype): a query whose
+ * bivx_filter::svtype is t meets only intervals of type t, at no cost per candidate, so ONE index serves sv2nl's three
+ * mappers where the reference builds a tree per (mapper, chromosome). Host / device pointers as for bivx_append*. */
+int bivx_append_typed(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
+                      const uint8_t *svtype, size_t n);
+int bivx_append_typed_dev(bivx_index *idx, const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
+                          const uint8_t *d_svtype, size_t n, void *stream);
 /* drops all intervals (keeps the allocation) */
 int bivx_clear(bivx_index *idx);
 
@@ -83,6 +93,11 @@ int bivx_is_built(const bivx_index *idx);
 size_t bivx_size(const bivx_index *idx);
 /* number of chromosome ids in use after build (max id + 1) */
 uint32_t bivx_num_chroms(const bivx_index *idx);
+
+/* largest svtype in the built index + 1 (1 when no interval carries a type) */
+uint32_t bivx_num_types(const bivx_index *idx);
+/* the svtype column by id (0xFF for ids out of range). Host pointers. */
+int bivx_get_svtypes(const bivx_index *idx, const uint32_t *ids, size_t n, uint8_t *svtype_out);
 
 /* reads back appended intervals by id (what the facade needs to materialise interval_type copies,
  * interval_tree.hpp:316). Host pointers; any output may be NULL. */
@@ -178,7 +193,8 @@ struct bivx_filter {
   uint32_t kind;
   uint32_t max_dist;   /* sv2nl --dis */
   uint32_t use_strand; /* sv2nl: !--short */
-  uint32_t reserved;
+  uint32_t svtype;     /* 0: intervals of every type; t in 1..255: only intervals appended with svtype t (a selection
+                          of index partitions, not a per-candidate test; valid with kind == BIVX_FILTER_NONE too) */
   const uint32_t *query_aux;
   const uint32_t *interval_aux;
 };

@@ -33,3 +33,52 @@ def test_facade_reference_cases_on_gpu(facade_binary):
     r = subprocess.run([facade_binary], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_find_overlap_choice_in_compatibility_mode(tmp_path, oracle):
+    """SURVEY.md §8 row f4: in HitOrder::ReferencePreorder the facade answers find_overlap with the reference's own
+    single descent (interval_tree.hpp:290-304) on the replayed tree — the same node as the oracle for every query, with the
+    same max(nullptr) == lowest() rule; the default mode returns the overlapping interval inserted first."""
+    import numpy as np
+    from binary_amd import _build
+    _build.build_lib()
+    exe = str(tmp_path / "facade_find_overlap")
+    libdir = os.path.join(ROOT, "binary_amd")
+    subprocess.run(["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "facade_find_overlap.cpp"), "-o", exe, "-L", libdir, "-lbivx",
+                    "-pthread", f"-Wl,-rpath,{libdir}"], check=True, capture_output=True, text=True)
+    rng = np.random.default_rng(2024)
+    for case, (n, q, span, maxlen) in enumerate([(10, 60, 40, 8), (500, 400, 3000, 60), (4000, 1500, 100000, 900)]):
+        low = rng.integers(0, span, n).astype(np.uint32)
+        high = (low + rng.integers(0, maxlen, n)).astype(np.uint32)
+        if case == 0:  # the reference's own fixture first (test_interval_tree.cpp:87-129)
+            low = np.array([16, 8, 5, 0, 6, 15, 25, 17, 19, 26], np.uint32)
+            high = np.array([21, 9, 8, 3, 10, 23, 30, 19, 20, 26], np.uint32)
+            n = 10
+        qlo = rng.integers(0, span + 20, q).astype(np.uint32)
+        qlo[::7] = 0                                    # the null-left quirk needs q.low == 0
+        qhi = (qlo + rng.integers(0, maxlen, q)).astype(np.uint32)
+        if case == 0:
+            qlo[0], qhi[0] = 22, 25                     # pinned by the reference: [15,23]
+        f = tmp_path / f"case{case}.txt"
+        with open(f, "w") as fh:
+            fh.write(f"{n} {q}\n")
+            fh.writelines(f"{a} {b}\n" for a, b in zip(low, high))
+            fh.writelines(f"{a} {b}\n" for a, b in zip(qlo, qhi))
+        r = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = r.stdout.strip().splitlines()
+        assert len(lines) == q
+        t = oracle.OracleTree(low, high)
+        for i, line in enumerate(lines):
+            ref, dflt = (x.strip() for x in line.split("|"))
+            node = t.find_overlap(int(qlo[i]), int(qhi[i]))
+            exp = "-" if node < 0 else f"{low[node]} {high[node]}"
+            assert ref == exp, (case, i, qlo[i], qhi[i], ref, exp)
+            hits = np.nonzero((low <= qhi[i]) & (high >= qlo[i]))[0]
+            assert dflt == ("-" if hits.size == 0 else f"{low[hits[0]]} {high[hits[0]]}")
+            # (for low <= high data the descent is exact on existence, CLRS 14.3; the choice is what differs)
+            assert (node < 0) == (hits.size == 0)
+        if case == 0:
+            assert lines[0].split("|")[0].strip() == "15 23"

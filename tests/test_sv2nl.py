@@ -96,8 +96,12 @@ def lines_of(path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra,tag", [((), ""), (("--dis", "50000", "-s"), "_short_dis50000")])
 @pytest.mark.parametrize("host_filter", [False, True])
-def test_tool_outputs_match_restatement(tools, tmp_path, extra, tag, host_filter):
-    out = run_tool(tools, tmp_path, extra + (("--host-filter",) if host_filter else ()))
+@pytest.mark.parametrize("per_mapper", [False, True])
+def test_tool_outputs_match_restatement(tools, tmp_path, extra, tag, host_filter, per_mapper):
+    """Default: ONE device index with an svtype column for the three mappers; --index-per-mapper:
+    round 1's three host-filtered indexes. Both must give the restatement's lines."""
+    out = run_tool(tools, tmp_path, extra + (("--host-filter",) if host_filter else ())
+                   + (("--index-per-mapper",) if per_mapper else ()))
     for k in ("dup", "inv", "tra"):
         assert lines_of(out + "." + k) == lines_of(os.path.join(VCF, f"pair_expected{tag}.{k}.tsv")), k
 
