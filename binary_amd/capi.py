@@ -14,7 +14,7 @@ E_INVALID, E_HIP, E_NOMEM, E_STATE, E_RANGE, E_TIMEOUT = -1, -2, -3, -4, -5, -6
 ABI_VERSION = 0x00020000
 
 EXPORTS = (
-    "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_destroy", "bivx_device", "bivx_append",
+    "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_create_sharded", "bivx_num_devices", "bivx_device_of_chrom", "bivx_destroy", "bivx_device", "bivx_append",
     "bivx_append_dev", "bivx_append_typed", "bivx_append_typed_dev", "bivx_num_types", "bivx_get_svtypes", "bivx_clear", "bivx_build", "bivx_is_built", "bivx_size", "bivx_num_chroms",
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
@@ -60,6 +60,9 @@ def load() -> C.CDLL:
     L.bivx_abi_version.restype = C.c_uint32
     L.bivx_last_error.restype = C.c_char_p
     L.bivx_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.bivx_create_sharded.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+    L.bivx_num_devices.argtypes = [vp]
+    L.bivx_device_of_chrom.argtypes = [vp, C.c_uint32]
     L.bivx_destroy.argtypes = [vp]
     L.bivx_destroy.restype = None
     L.bivx_device.argtypes = [vp]

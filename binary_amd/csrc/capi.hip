@@ -34,6 +34,8 @@ void set_error(const char *fmt, ...) {
 using namespace bivx;
 
 struct bivx_index {
+  // a handle made by bivx_create_sharded owns one ordinary index per device instead of what follows (sharded.cpp)
+  bivx::ShardedState *sharded = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
   // append-order copy (what RbTree::insert_node received, in order)
@@ -73,6 +75,15 @@ struct bivx_index {
   mutable std::multimap<size_t, void *> cache_free;  // block size -> block
   mutable size_t cache_bytes = 0;
 };
+
+// the device-pointer entry points address ONE device's memory: a sharded handle has no meaning for them
+#define BIVX_NOT_SHARDED(idx, who)                                                                         \
+  if ((idx) && (idx)->sharded) {                                                                           \
+    set_error("%s: a sharded index takes host pointers (bivx_find_overlaps, bivx_count, bivx_fill, "      \
+              "bivx_any); device pointers belong to one device",                                           \
+              who);                                                                                        \
+    return BIVX_E_STATE;                                                                                   \
+  }
 
 namespace {
 
@@ -436,6 +447,7 @@ int check_query_args(const bivx_index *idx, const void *qlow, const void *qhigh,
     set_error("%s: null argument", who);
     return BIVX_E_INVALID;
   }
+  BIVX_NOT_SHARDED(idx, who);
   if (!idx->built) {
     set_error("%s: index not built (call bivx_build after the last append)", who);
     return BIVX_E_STATE;
@@ -493,8 +505,40 @@ int bivx_create(bivx_index **out, int device) {
   return 0;
 }
 
+int bivx_create_sharded(bivx_index **out, const int *devices, int ndev) {
+  if (!out) {
+    set_error("bivx_create_sharded: null out");
+    return BIVX_E_INVALID;
+  }
+  *out = nullptr;
+  ShardedState *st = nullptr;
+  BIVX_TRY(sharded_create(&st, devices, ndev));
+  bivx_index *idx = new (std::nothrow) bivx_index();
+  if (!idx) {
+    sharded_destroy(st);
+    set_error("bivx_create_sharded: out of host memory");
+    return BIVX_E_NOMEM;
+  }
+  idx->sharded = st;
+  idx->device = devices[0];
+  *out = idx;
+  return 0;
+}
+
+int bivx_num_devices(const bivx_index *idx) { return !idx ? 0 : idx->sharded ? sharded_num_devices(idx->sharded) : 1; }
+
+int bivx_device_of_chrom(const bivx_index *idx, uint32_t chrom) {
+  if (!idx) return -1;
+  return idx->sharded ? sharded_device_of_chrom(idx->sharded, chrom) : idx->device;
+}
+
 void bivx_destroy(bivx_index *idx) {
   if (!idx) return;
+  if (idx->sharded) {
+    sharded_destroy(idx->sharded);
+    delete idx;
+    return;
+  }
   DeviceGuard g(idx->device);
   if (idx->stream) (void)hipStreamSynchronize(idx->stream);
   (void)hipDeviceSynchronize();
@@ -513,21 +557,25 @@ void bivx_destroy(bivx_index *idx) {
 int bivx_device(const bivx_index *idx) { return idx ? idx->device : -1; }
 
 int bivx_append(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high, size_t n) {
+  if (idx && idx->sharded) return sharded_append(idx->sharded, chrom, low, high, nullptr, n);
   return append_impl(idx, chrom, low, high, nullptr, n, hipMemcpyHostToDevice, idx ? idx->stream : nullptr);
 }
 
 int bivx_append_typed(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
                       const uint8_t *svtype, size_t n) {
+  if (idx && idx->sharded) return sharded_append(idx->sharded, chrom, low, high, svtype, n);
   return append_impl(idx, chrom, low, high, svtype, n, hipMemcpyHostToDevice, idx ? idx->stream : nullptr);
 }
 
 int bivx_append_dev(bivx_index *idx, const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
                     size_t n, void *stream) {
+  BIVX_NOT_SHARDED(idx, "bivx_append_dev");
   return append_impl(idx, d_chrom, d_low, d_high, nullptr, n, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
 }
 
 int bivx_append_typed_dev(bivx_index *idx, const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
                           const uint8_t *d_svtype, size_t n, void *stream) {
+  BIVX_NOT_SHARDED(idx, "bivx_append_typed_dev");
   return append_impl(idx, d_chrom, d_low, d_high, d_svtype, n, hipMemcpyDeviceToDevice,
                      static_cast<hipStream_t>(stream));
 }
@@ -537,6 +585,7 @@ int bivx_clear(bivx_index *idx) {
     set_error("bivx_clear: null index");
     return BIVX_E_INVALID;
   }
+  if (idx->sharded) return sharded_clear(idx->sharded);
   BIVX_GUARD(idx);
   BIVX_HIP(hipStreamSynchronize(idx->stream));
   free_built(idx);
@@ -550,6 +599,7 @@ int bivx_build(bivx_index *idx) {
     set_error("bivx_build: null index");
     return BIVX_E_INVALID;
   }
+  if (idx->sharded) return sharded_build(idx->sharded);
   if (idx->built && idx->built_n == idx->n) return 0;
   BIVX_GUARD(idx);
   const auto t0 = std::chrono::steady_clock::now();
@@ -690,10 +740,17 @@ int bivx_build(bivx_index *idx) {
   return 0;
 }
 
-int bivx_is_built(const bivx_index *idx) { return idx && idx->built && idx->built_n == idx->n; }
-size_t bivx_size(const bivx_index *idx) { return idx ? idx->n : 0; }
-uint32_t bivx_num_chroms(const bivx_index *idx) { return idx ? idx->nchrom : 0; }
-uint32_t bivx_num_types(const bivx_index *idx) { return idx ? idx->ntypes : 0; }
+int bivx_is_built(const bivx_index *idx) {
+  if (idx && idx->sharded) return sharded_is_built(idx->sharded);
+  return idx && idx->built && idx->built_n == idx->n;
+}
+size_t bivx_size(const bivx_index *idx) { return !idx ? 0 : idx->sharded ? sharded_size(idx->sharded) : idx->n; }
+uint32_t bivx_num_chroms(const bivx_index *idx) {
+  return !idx ? 0 : idx->sharded ? sharded_num_chroms(idx->sharded) : idx->nchrom;
+}
+uint32_t bivx_num_types(const bivx_index *idx) {
+  return !idx ? 0 : idx->sharded ? sharded_num_types(idx->sharded) : idx->ntypes;
+}
 
 int bivx_get_svtypes(const bivx_index *idx, const uint32_t *ids, size_t n, uint8_t *svtype_out) {
   if (!idx || (n && (!ids || !svtype_out))) {
@@ -701,6 +758,7 @@ int bivx_get_svtypes(const bivx_index *idx, const uint32_t *ids, size_t n, uint8
     return BIVX_E_INVALID;
   }
   if (n == 0) return 0;
+  if (idx->sharded) return sharded_get_svtypes(idx->sharded, ids, n, svtype_out);
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
   TempPool tmp(idx);
@@ -722,6 +780,7 @@ int bivx_get_intervals(const bivx_index *idx, const uint32_t *ids, size_t n, uin
     return BIVX_E_INVALID;
   }
   if (n == 0) return 0;
+  if (idx->sharded) return sharded_get_intervals(idx->sharded, ids, n, chrom_out, low_out, high_out);
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
   TempPool tmp(idx);
@@ -869,6 +928,7 @@ int bivx_stream_status(const bivx_index *idx, void *stream) {
     set_error("bivx_stream_status: null index");
     return BIVX_E_INVALID;
   }
+  BIVX_NOT_SHARDED(idx, "bivx_stream_status");
   BIVX_GUARD(idx);
   BIVX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return report_device_errors(idx, "bivx_stream_status");
@@ -879,6 +939,7 @@ int bivx_debug_corrupt_workspace(const bivx_index *idx, void *stream) {
     set_error("bivx_debug_corrupt_workspace: null index");
     return BIVX_E_INVALID;
   }
+  BIVX_NOT_SHARDED(idx, "bivx_debug_corrupt_workspace");
   BIVX_GUARD(idx);
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(idx->ws_mutex);
@@ -896,6 +957,7 @@ int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_
     set_error("bivx_sort_hits_dev: null argument");
     return BIVX_E_INVALID;
   }
+  BIVX_NOT_SHARDED(idx, "bivx_sort_hits_dev");
   BIVX_GUARD(idx);
   return launch_sort_hits(d_offsets, d_hit_ids, q, ~0ull, static_cast<hipStream_t>(stream));
 }
@@ -1016,6 +1078,13 @@ int bivx_count(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *ql
 
 int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
                  const bivx_filter *filter, uint64_t *offsets_out) {
+  if (idx && idx->sharded) {
+    if ((q && (!qlow || !qhigh)) || !offsets_out) {
+      set_error("bivx_count: null argument");
+      return BIVX_E_INVALID;
+    }
+    return sharded_count(idx->sharded, qchrom, qlow, qhigh, q, filter, offsets_out);
+  }
   BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_count"));
   if (!offsets_out) {
     set_error("bivx_count: null offsets_out");
@@ -1047,6 +1116,13 @@ int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlo
 
 int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
                 const bivx_filter *filter, const uint64_t *offsets, uint32_t *hit_ids_out, int sort_by_id) {
+  if (idx && idx->sharded) {
+    if (q && (!qlow || !qhigh || !offsets || (offsets[q] && !hit_ids_out))) {
+      set_error("bivx_fill: null argument");
+      return BIVX_E_INVALID;
+    }
+    return q ? sharded_fill(idx->sharded, qchrom, qlow, qhigh, q, filter, offsets, hit_ids_out, sort_by_id) : 0;
+  }
   BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_fill"));
   if (q == 0) return 0;
   if (!offsets) {
@@ -1080,6 +1156,13 @@ int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *q
 int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                        size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
                        uint32_t **hit_ids_out) {
+  if (idx && idx->sharded) {
+    if ((q && (!qlow || !qhigh)) || !offsets_out || !hit_ids_out) {
+      set_error("bivx_find_overlaps: null argument");
+      return BIVX_E_INVALID;
+    }
+    return sharded_find_overlaps(idx->sharded, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
+  }
   BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_find_overlaps"));
   if (!offsets_out || !hit_ids_out) {
     set_error("bivx_find_overlaps: null output");
@@ -1134,6 +1217,13 @@ void bivx_free(void *p) { std::free(p); }
 
 int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
              uint32_t *first_id_out) {
+  if (idx && idx->sharded) {
+    if (q && (!qlow || !qhigh || !first_id_out)) {
+      set_error("bivx_any: null argument");
+      return BIVX_E_INVALID;
+    }
+    return q ? sharded_any(idx->sharded, qchrom, qlow, qhigh, q, first_id_out) : 0;
+  }
   BIVX_TRY(check_query_args(idx, qlow, qhigh, q, "bivx_any"));
   if (q == 0) return 0;
   if (!first_id_out) {
@@ -1157,6 +1247,10 @@ int bivx_get_stats(const bivx_index *idx, bivx_stats *out) {
   if (!idx || !out) {
     set_error("bivx_get_stats: null argument");
     return BIVX_E_INVALID;
+  }
+  if (idx->sharded) {
+    sharded_stats(idx->sharded, out);
+    return 0;
   }
   memset(out, 0, sizeof(*out));
   out->n_intervals = idx->n;

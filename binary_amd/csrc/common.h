@@ -80,6 +80,35 @@ struct BinStats {
   uint32_t n_inverted;  // entries with low > high
 };
 
+// ---- sharded.cpp: one index over several devices (bivx_create_sharded); capi.hip dispatches to these ---------
+struct ShardedState;
+int sharded_create(ShardedState **out, const int *devices, int ndev);
+void sharded_destroy(ShardedState *st);
+int sharded_num_devices(const ShardedState *st);
+int sharded_device_of_chrom(const ShardedState *st, uint32_t chrom);
+int sharded_append(ShardedState *st, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
+                   const uint8_t *svtype, size_t n);
+int sharded_clear(ShardedState *st);
+size_t sharded_size(const ShardedState *st);
+bool sharded_is_built(const ShardedState *st);
+uint32_t sharded_num_chroms(const ShardedState *st);
+uint32_t sharded_num_types(const ShardedState *st);
+int sharded_build(ShardedState *st);
+int sharded_get_intervals(const ShardedState *st, const uint32_t *ids, size_t n, uint32_t *chrom_out,
+                          uint32_t *low_out, uint32_t *high_out);
+int sharded_get_svtypes(const ShardedState *st, const uint32_t *ids, size_t n, uint8_t *out);
+int sharded_find_overlaps(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                          size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+                          uint32_t **hit_ids_out);
+int sharded_count(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                  size_t q, const bivx_filter *filter, uint64_t *offsets_out);
+int sharded_fill(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                 size_t q, const bivx_filter *filter, const uint64_t *offsets, uint32_t *hit_ids_out,
+                 int sort_by_id);
+int sharded_any(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                size_t q, uint32_t *first_id_out);
+void sharded_stats(const ShardedState *st, bivx_stats *out);
+
 // ---- scan.hip ---------------------------------------------------------------------------------------
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = total. scratch: scan_scratch_bytes(n).
 size_t scan_scratch_bytes(size_t n);

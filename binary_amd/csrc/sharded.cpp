@@ -1,0 +1,421 @@
+// sharded.cpp — one index over several GPUs of a node, behind the same handle and the same host-pointer entry points
+// (include/bivx.h, bivx_create_sharded). Plain host C++ on top of the library's own C ABI: every shard is an ordinary
+// single-device bivx_index; this file only routes.
+//
+// Decomposition (the reference's only one: one task per chromosome, standalone/sv2nl/include/mapper.hpp:238-246):
+// whole chromosomes are assigned to devices by LPT on n_c * log2(n_c); a query goes to the device
+// that holds its chromosome; nothing is exchanged between devices. An index with fewer populated chromosomes than
+// devices (a plain IntervalTree has one) is replicated instead and the QUERIES are split into contiguous ranges.
+// One host thread per device drives its shard; results land in the caller's host arrays in query order, with
+// global (append-order) interval ids.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace bivx {
+
+struct ShardedState {
+  std::vector<int> devices;
+  std::vector<bivx_index *> shard;
+  // everything appended, in append order (ids are indices into these)
+  std::vector<uint32_t> chrom, low, high;
+  std::vector<uint8_t> type;
+  bool typed = false, built = false, by_chrom = false;
+  size_t built_n = 0;
+  uint32_t nchrom = 0, ntypes = 1;
+  std::vector<uint32_t> chrom_shard;         // by_chrom: chromosome -> shard (0xFFFFFFFF: no interval there)
+  std::vector<std::vector<uint32_t>> gid;    // by_chrom: shard-local id -> global id
+  double build_ms = 0.0;
+};
+
+namespace {
+
+template <typename F>
+int on_every_shard(const ShardedState *st, F &&f) {
+  const size_t k = st->shard.size();
+  std::vector<int> rc(k, 0);
+  std::vector<std::string> err(k);
+  std::vector<std::thread> th;
+  for (size_t s = 0; s < k; ++s)
+    th.emplace_back([&, s] {
+      rc[s] = f(s);
+      if (rc[s] != 0) err[s] = bivx_last_error();  // thread-local text: carry it over to the caller's thread
+    });
+  for (auto &t : th) t.join();
+  for (size_t s = 0; s < k; ++s)
+    if (rc[s] != 0) {
+      set_error("shard %zu (device %d): %s", s, st->devices[s], err[s].c_str());
+      return rc[s];
+    }
+  return 0;
+}
+
+// which shard answers query i, and the query lists per shard
+struct Route {
+  std::vector<std::vector<uint32_t>> qs;  // per shard: indices of its queries, ascending
+};
+
+int route(const ShardedState *st, const uint32_t *qchrom, size_t q, Route &r) {
+  const size_t k = st->shard.size();
+  r.qs.assign(k, {});
+  if (q > 0xFFFFFFFFull) {
+    set_error("sharded index: more than 2^32 queries in one call");
+    return BIVX_E_RANGE;
+  }
+  if (st->by_chrom) {
+    for (size_t i = 0; i < q; ++i) {
+      const uint32_t c = qchrom ? qchrom[i] : 0u;
+      const uint32_t s = c < st->chrom_shard.size() ? st->chrom_shard[c] : 0xFFFFFFFFu;
+      if (s != 0xFFFFFFFFu) r.qs[s].push_back((uint32_t)i);
+    }
+  } else {  // replicated index: contiguous query ranges
+    for (size_t s = 0; s < k; ++s) {
+      const size_t a = q * s / k, b = q * (s + 1) / k;
+      r.qs[s].resize(b - a);
+      std::iota(r.qs[s].begin(), r.qs[s].end(), (uint32_t)a);
+    }
+  }
+  return 0;
+}
+
+struct SubBatch {
+  std::vector<uint32_t> c, lo, hi, aux;
+  bivx_filter flt{};
+};
+
+// a shard's part of the batch (and of the filter's per-query words; per-interval words are remapped to local ids)
+void gather(const ShardedState *st, size_t s, const std::vector<uint32_t> &qs, const uint32_t *qchrom,
+            const uint32_t *qlow, const uint32_t *qhigh, const bivx_filter *f, SubBatch &b,
+            std::vector<uint32_t> &iaux_local) {
+  const size_t m = qs.size();
+  b.lo.resize(m);
+  b.hi.resize(m);
+  if (qchrom) b.c.resize(m);
+  for (size_t j = 0; j < m; ++j) {
+    b.lo[j] = qlow[qs[j]];
+    b.hi[j] = qhigh[qs[j]];
+    if (qchrom) b.c[j] = qchrom[qs[j]];
+  }
+  if (f) {
+    b.flt = *f;
+    if (f->query_aux) {
+      b.aux.resize(m);
+      for (size_t j = 0; j < m; ++j) b.aux[j] = f->query_aux[qs[j]];
+      b.flt.query_aux = b.aux.data();
+    }
+    if (f->interval_aux && st->by_chrom) {
+      const auto &g = st->gid[s];
+      iaux_local.resize(g.size());
+      for (size_t j = 0; j < g.size(); ++j) iaux_local[j] = f->interval_aux[g[j]];
+      b.flt.interval_aux = iaux_local.data();
+    }
+  }
+}
+
+}  // namespace
+
+int sharded_create(ShardedState **out, const int *devices, int ndev) {
+  if (!devices || ndev < 1) {
+    set_error("bivx_create_sharded: need at least one device");
+    return BIVX_E_INVALID;
+  }
+  auto st = std::make_unique<ShardedState>();
+  for (int i = 0; i < ndev; ++i) {
+    bivx_index *ix = nullptr;
+    const int rc = bivx_create(&ix, devices[i]);
+    if (rc != 0) {
+      for (auto *p : st->shard) bivx_destroy(p);
+      return rc;
+    }
+    st->devices.push_back(devices[i]);
+    st->shard.push_back(ix);
+  }
+  *out = st.release();
+  return 0;
+}
+
+void sharded_destroy(ShardedState *st) {
+  if (!st) return;
+  for (auto *p : st->shard) bivx_destroy(p);
+  delete st;
+}
+
+int sharded_num_devices(const ShardedState *st) { return (int)st->shard.size(); }
+int sharded_device_of_chrom(const ShardedState *st, uint32_t chrom) {
+  if (!st->built) return -1;
+  if (!st->by_chrom) return st->devices[0];
+  if (chrom >= st->chrom_shard.size() || st->chrom_shard[chrom] == 0xFFFFFFFFu) return -1;
+  return st->devices[st->chrom_shard[chrom]];
+}
+
+int sharded_append(ShardedState *st, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
+                   const uint8_t *svtype, size_t n) {
+  if (n && (!low || !high)) {
+    set_error("bivx_append: null argument");
+    return BIVX_E_INVALID;
+  }
+  if (st->low.size() + n >= 0xFFFFFFFFull) {
+    set_error("too many intervals (ids are uint32)");
+    return BIVX_E_RANGE;
+  }
+  const size_t old = st->low.size();
+  st->low.insert(st->low.end(), low, low + n);
+  st->high.insert(st->high.end(), high, high + n);
+  if (chrom) st->chrom.insert(st->chrom.end(), chrom, chrom + n);
+  else st->chrom.resize(old + n, 0u);
+  if (svtype) {
+    st->type.insert(st->type.end(), svtype, svtype + n);
+    st->typed = true;
+  } else {
+    st->type.resize(old + n, 0);
+  }
+  st->built = false;
+  return 0;
+}
+
+int sharded_clear(ShardedState *st) {
+  st->chrom.clear();
+  st->low.clear();
+  st->high.clear();
+  st->type.clear();
+  st->typed = st->built = false;
+  st->built_n = 0;
+  for (auto *p : st->shard) BIVX_TRY(bivx_clear(p));
+  return 0;
+}
+
+size_t sharded_size(const ShardedState *st) { return st->low.size(); }
+bool sharded_is_built(const ShardedState *st) { return st->built && st->built_n == st->low.size(); }
+uint32_t sharded_num_chroms(const ShardedState *st) { return st->nchrom; }
+uint32_t sharded_num_types(const ShardedState *st) { return st->ntypes; }
+
+int sharded_build(ShardedState *st) {
+  if (sharded_is_built(st)) return 0;
+  const size_t n = st->low.size(), k = st->shard.size();
+  uint32_t nchrom = 0, max_type = 0;
+  for (size_t i = 0; i < n; ++i) {
+    nchrom = std::max(nchrom, st->chrom[i] + 1);
+    max_type = std::max<uint32_t>(max_type, st->type[i]);
+  }
+  if (n && nchrom > BIVX_MAX_CHROMS) {
+    set_error("chromosome id %u exceeds BIVX_MAX_CHROMS", nchrom - 1);
+    return BIVX_E_RANGE;
+  }
+  std::vector<uint64_t> cnt(nchrom, 0);
+  for (size_t i = 0; i < n; ++i) ++cnt[st->chrom[i]];
+  const size_t populated = (size_t)std::count_if(cnt.begin(), cnt.end(), [](uint64_t c) { return c != 0; });
+  st->by_chrom = k > 1 && populated >= k;
+  st->chrom_shard.assign(nchrom, 0xFFFFFFFFu);
+  st->gid.assign(k, {});
+  std::vector<std::vector<uint32_t>> ids(k);  // global ids per shard, ascending (append order is kept inside a shard)
+  if (st->by_chrom) {
+    // LPT: heaviest chromosome to the least loaded device; ties to the lower chromosome id / lower device
+    std::vector<uint32_t> order;
+    for (uint32_t c = 0; c < nchrom; ++c)
+      if (cnt[c]) order.push_back(c);
+    auto weight = [&](uint32_t c) { return (double)cnt[c] * std::log2((double)cnt[c] + 2.0); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight(a) > weight(b); });
+    std::vector<double> load(k, 0.0);
+    for (uint32_t c : order) {
+      const size_t s = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+      st->chrom_shard[c] = (uint32_t)s;
+      load[s] += weight(c);
+    }
+    for (size_t i = 0; i < n; ++i) ids[st->chrom_shard[st->chrom[i]]].push_back((uint32_t)i);
+  } else {
+    for (size_t s = 0; s < k; ++s) {
+      ids[s].resize(n);
+      std::iota(ids[s].begin(), ids[s].end(), 0u);
+    }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  BIVX_TRY(on_every_shard(st, [&](size_t s) -> int {
+    const auto &g = ids[s];
+    std::vector<uint32_t> c(g.size()), lo(g.size()), hi(g.size());
+    std::vector<uint8_t> ty(g.size());
+    for (size_t j = 0; j < g.size(); ++j) {
+      c[j] = st->chrom[g[j]];
+      lo[j] = st->low[g[j]];
+      hi[j] = st->high[g[j]];
+      ty[j] = st->type[g[j]];
+    }
+    BIVX_TRY(bivx_clear(st->shard[s]));
+    if (st->typed) BIVX_TRY(bivx_append_typed(st->shard[s], c.data(), lo.data(), hi.data(), ty.data(), g.size()));
+    else BIVX_TRY(bivx_append(st->shard[s], c.data(), lo.data(), hi.data(), g.size()));
+    return bivx_build(st->shard[s]);
+  }));
+  st->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (st->by_chrom) st->gid = std::move(ids);
+  st->nchrom = nchrom;
+  st->ntypes = st->typed ? max_type + 1 : 1;
+  st->built = true;
+  st->built_n = n;
+  return 0;
+}
+
+int sharded_get_intervals(const ShardedState *st, const uint32_t *ids, size_t n, uint32_t *chrom_out,
+                          uint32_t *low_out, uint32_t *high_out) {
+  for (size_t i = 0; i < n; ++i) {
+    const bool ok = ids[i] < st->low.size();
+    if (chrom_out) chrom_out[i] = ok ? st->chrom[ids[i]] : 0xFFFFFFFFu;
+    if (low_out) low_out[i] = ok ? st->low[ids[i]] : 0xFFFFFFFFu;
+    if (high_out) high_out[i] = ok ? st->high[ids[i]] : 0u;
+  }
+  return 0;
+}
+
+int sharded_get_svtypes(const ShardedState *st, const uint32_t *ids, size_t n, uint8_t *out) {
+  for (size_t i = 0; i < n; ++i) out[i] = ids[i] < st->type.size() ? st->type[ids[i]] : (uint8_t)0xFF;
+  return 0;
+}
+
+// the whole batch: every shard answers its queries (bivx_find_overlaps), the CSR is assembled in query order
+int sharded_find_overlaps(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                          size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+                          uint32_t **hit_ids_out) {
+  *hit_ids_out = nullptr;
+  if (!sharded_is_built(st)) {
+    set_error("bivx_find_overlaps: index not built (call bivx_build after the last append)");
+    return BIVX_E_STATE;
+  }
+  const size_t k = st->shard.size();
+  Route r;
+  BIVX_TRY(route(st, qchrom, q, r));
+  std::vector<std::vector<uint64_t>> off(k);
+  std::vector<uint32_t *> hits(k, nullptr);
+  struct Freer {
+    std::vector<uint32_t *> &h;
+    ~Freer() {
+      for (auto *p : h) bivx_free(p);
+    }
+  } freer{hits};
+  BIVX_TRY(on_every_shard(st, [&](size_t s) -> int {
+    SubBatch b;
+    std::vector<uint32_t> iaux;
+    gather(st, s, r.qs[s], qchrom, qlow, qhigh, filter, b, iaux);
+    off[s].assign(r.qs[s].size() + 1, 0);
+    if (r.qs[s].empty()) return 0;
+    return bivx_find_overlaps(st->shard[s], qchrom ? b.c.data() : nullptr, b.lo.data(), b.hi.data(), r.qs[s].size(),
+                              filter ? &b.flt : nullptr, sort_by_id, off[s].data(), &hits[s]);
+  }));
+  std::fill(offsets_out, offsets_out + q + 1, 0ull);
+  for (size_t s = 0; s < k; ++s)
+    for (size_t j = 0; j < r.qs[s].size(); ++j) offsets_out[r.qs[s][j] + 1] = off[s][j + 1] - off[s][j];
+  for (size_t i = 0; i < q; ++i) offsets_out[i + 1] += offsets_out[i];
+  const uint64_t total = offsets_out[q];
+  if (total == 0) return 0;
+  uint32_t *out = static_cast<uint32_t *>(std::malloc((size_t)total * sizeof(uint32_t)));
+  if (!out) {
+    set_error("bivx_find_overlaps: out of host memory for %llu hit ids", (unsigned long long)total);
+    return BIVX_E_NOMEM;
+  }
+  // Shard-local ids ascend with the global ones (a shard keeps append order), so a list that is ascending locally is
+  // ascending globally: sort_by_id needs no second look.
+  (void)on_every_shard(st, [&](size_t s) -> int {
+    const uint32_t *g = st->by_chrom ? st->gid[s].data() : nullptr;
+    for (size_t j = 0; j < r.qs[s].size(); ++j) {
+      uint32_t *dst = out + offsets_out[r.qs[s][j]];
+      const uint32_t *src = hits[s] + off[s][j];
+      const size_t m = (size_t)(off[s][j + 1] - off[s][j]);
+      if (g) for (size_t x = 0; x < m; ++x) dst[x] = g[src[x]];
+      else std::memcpy(dst, src, m * sizeof(uint32_t));
+    }
+    return 0;
+  });
+  *hit_ids_out = out;
+  return 0;
+}
+
+int sharded_count(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                  size_t q, const bivx_filter *filter, uint64_t *offsets_out) {
+  if (!sharded_is_built(st)) {
+    set_error("bivx_count: index not built (call bivx_build after the last append)");
+    return BIVX_E_STATE;
+  }
+  const size_t k = st->shard.size();
+  Route r;
+  BIVX_TRY(route(st, qchrom, q, r));
+  std::vector<std::vector<uint64_t>> off(k);
+  BIVX_TRY(on_every_shard(st, [&](size_t s) -> int {
+    SubBatch b;
+    std::vector<uint32_t> iaux;
+    gather(st, s, r.qs[s], qchrom, qlow, qhigh, filter, b, iaux);
+    off[s].assign(r.qs[s].size() + 1, 0);
+    if (r.qs[s].empty()) return 0;
+    return bivx_count_f(st->shard[s], qchrom ? b.c.data() : nullptr, b.lo.data(), b.hi.data(), r.qs[s].size(),
+                        filter ? &b.flt : nullptr, off[s].data());
+  }));
+  std::fill(offsets_out, offsets_out + q + 1, 0ull);
+  for (size_t s = 0; s < k; ++s)
+    for (size_t j = 0; j < r.qs[s].size(); ++j) offsets_out[r.qs[s][j] + 1] = off[s][j + 1] - off[s][j];
+  for (size_t i = 0; i < q; ++i) offsets_out[i + 1] += offsets_out[i];
+  return 0;
+}
+
+int sharded_fill(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                 size_t q, const bivx_filter *filter, const uint64_t *offsets, uint32_t *hit_ids_out,
+                 int sort_by_id) {
+  // the offsets are the caller's; the ids are what bivx_find_overlaps gives for the same batch
+  std::vector<uint64_t> off(q + 1);
+  uint32_t *hits = nullptr;
+  BIVX_TRY(sharded_find_overlaps(st, qchrom, qlow, qhigh, q, filter, sort_by_id, off.data(), &hits));
+  int rc = 0;
+  if (std::memcmp(off.data(), offsets, (q + 1) * sizeof(uint64_t)) != 0) {
+    set_error("bivx_fill: offsets do not belong to this batch");
+    rc = BIVX_E_INVALID;
+  } else if (off[q]) {
+    std::memcpy(hit_ids_out, hits, (size_t)off[q] * sizeof(uint32_t));
+  }
+  bivx_free(hits);
+  return rc;
+}
+
+int sharded_any(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                size_t q, uint32_t *first_id_out) {
+  if (!sharded_is_built(st)) {
+    set_error("bivx_any: index not built (call bivx_build after the last append)");
+    return BIVX_E_STATE;
+  }
+  Route r;
+  BIVX_TRY(route(st, qchrom, q, r));
+  std::fill(first_id_out, first_id_out + q, BIVX_NO_HIT);
+  return on_every_shard(st, [&](size_t s) -> int {
+    if (r.qs[s].empty()) return 0;
+    SubBatch b;
+    std::vector<uint32_t> iaux;
+    gather(st, s, r.qs[s], qchrom, qlow, qhigh, nullptr, b, iaux);
+    std::vector<uint32_t> first(r.qs[s].size());
+    BIVX_TRY(bivx_any(st->shard[s], qchrom ? b.c.data() : nullptr, b.lo.data(), b.hi.data(), r.qs[s].size(),
+                      first.data()));
+    for (size_t j = 0; j < r.qs[s].size(); ++j)
+      if (first[j] != BIVX_NO_HIT) first_id_out[r.qs[s][j]] = st->by_chrom ? st->gid[s][first[j]] : first[j];
+    return 0;
+  });
+}
+
+void sharded_stats(const ShardedState *st, bivx_stats *out) {
+  std::memset(out, 0, sizeof(*out));
+  out->n_intervals = st->low.size();
+  out->n_chroms = st->nchrom;
+  out->build_ms = st->build_ms;
+  for (auto *p : st->shard) {
+    bivx_stats s;
+    if (bivx_get_stats(p, &s) != 0) continue;
+    out->n_segments += s.n_segments;
+    out->n_cells += s.n_cells;
+    out->index_bytes += s.index_bytes;
+    out->staging_bytes += s.staging_bytes;
+    out->prefix_timeouts += s.prefix_timeouts;
+  }
+}
+
+}  // namespace bivx

@@ -48,12 +48,19 @@ def _check_dev_tensor(t, name, n=None, itemsize=4):
 class IntervalIndex:
     """Batched drop-in for IntervalTree<UIntIntervalNode> (+ a chromosome id per interval/query)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0):
+        """device: a HIP device ordinal, or a sequence of them for an index sharded by chromosome over several GPUs
+        of the node (bivx_create_sharded; host-array entry points only)."""
         self._L = capi.load()
         h = C.c_void_p()
-        capi.check(self._L.bivx_create(C.byref(h), int(device)))
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*[int(d) for d in device])
+            capi.check(self._L.bivx_create_sharded(C.byref(h), devs, len(device)))
+            self.device = int(device[0])
+        else:
+            capi.check(self._L.bivx_create(C.byref(h), int(device)))
+            self.device = int(device)
         self._h = h
-        self.device = int(device)
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
@@ -117,6 +124,12 @@ class IntervalIndex:
 
     def num_chroms(self) -> int:
         return int(self._L.bivx_num_chroms(self._h))
+
+    def num_devices(self) -> int:
+        return int(self._L.bivx_num_devices(self._h))
+
+    def device_of_chrom(self, chrom: int) -> int:
+        return int(self._L.bivx_device_of_chrom(self._h, int(chrom)))
 
     def num_types(self) -> int:
         return int(self._L.bivx_num_types(self._h))

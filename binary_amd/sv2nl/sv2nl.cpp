@@ -102,6 +102,7 @@ namespace sv2nl {
     int threads{NUM_THREADS};
     bool short_reads{false}, merge{false}, debug{false}, host_filter{false}, index_per_mapper{false};
     int device{0};
+    std::vector<int> devices;  // --devices: shard the index by chromosome over these GPUs (bivx_create_sharded)
   };
 
   enum class Kind { Dup, Inv, Tra };
@@ -156,7 +157,12 @@ namespace sv2nl {
       sh.items.push_back(std::move(s));
     }
     if (sh.items.empty()) return;
-    if (bivx_create(&sh.ix, opt.device) != 0) die_bivx("bivx_create");
+    if (opt.devices.size() > 1) {
+      if (bivx_create_sharded(&sh.ix, opt.devices.data(), static_cast<int>(opt.devices.size())) != 0)
+        die_bivx("bivx_create_sharded");
+    } else if (bivx_create(&sh.ix, opt.device) != 0) {
+      die_bivx("bivx_create");
+    }
     if (bivx_append_typed(sh.ix, ic.data(), ilo.data(), ihi.data(), ity.data(), sh.items.size()) != 0)
       die_bivx("bivx_append_typed");
     if (bivx_build(sh.ix) != 0) die_bivx("bivx_build");
@@ -396,6 +402,7 @@ namespace sv2nl {
            "  -h, --help            Print help\n"
            "  -v, --version         Print the current version number\n"
            "      --device arg      HIP device ordinal (default: 0 or $BIVX_DEVICE)\n"
+           "      --devices arg     Comma-separated HIP device ordinals: one index sharded by chromosome over them\n"
            "      --host-filter     Evaluate check_condition on the host instead of on the device\n"
            "      --index-per-mapper  One device index per mapper instead of one typed index for all three\n";
   }
@@ -450,6 +457,16 @@ int main(int argc, char **argv) {
       opt.debug = true;
     } else if (a == "--device") {
       opt.device = std::stoi(value("device"));
+    } else if (a == "--devices") {
+      std::string list = value("devices");
+      for (std::size_t b = 0; b <= list.size();) {
+        const std::size_t e = list.find(',', b);
+        const std::string tok = list.substr(b, e == std::string::npos ? std::string::npos : e - b);
+        if (!tok.empty()) opt.devices.push_back(std::stoi(tok));
+        if (e == std::string::npos) break;
+        b = e + 1;
+      }
+      if (!opt.devices.empty()) opt.device = opt.devices[0];
     } else if (a == "--host-filter") {
       opt.host_filter = true;
     } else if (a == "--index-per-mapper") {

@@ -192,6 +192,13 @@ namespace binary::algorithm::tree {
       detail::check(bivx_create(&h, device), "bivx_create");
       index_.reset(h);
     }
+    /// One tree over several GPUs of the node (bivx_create_sharded): a plain tree has a single "chromosome", so the
+    /// index is replicated on every device and each batch of queries is split between them.
+    explicit IntervalTree(std::span<const int> devices) {
+      bivx_index *h = nullptr;
+      detail::check(bivx_create_sharded(&h, devices.data(), static_cast<int>(devices.size())), "bivx_create_sharded");
+      index_.reset(h);
+    }
     IntervalTree(IntervalTree &&) noexcept = default;
     auto operator=(IntervalTree &&) noexcept -> IntervalTree & = default;
     IntervalTree(const IntervalTree &) = delete;

@@ -62,6 +62,20 @@ int bivx_create(bivx_index **out, int device);
 void bivx_destroy(bivx_index *idx);
 int bivx_device(const bivx_index *idx);
 
+/* ---- several GPUs of one node behind one handle ------------------------------------------------------
+ * replaces: the reference's only decomposition, one task per chromosome on a thread pool
+ * (standalone/sv2nl/include/mapper.hpp:238-246, main.cpp:34-44). Whole chromosomes are assigned to the ndev devices by
+ * LPT on their interval counts; a query is answered by the device that holds its chromosome; no data
+ * moves between devices. An index with fewer populated chromosomes than devices (a plain IntervalTree has one) is
+ * replicated on every device and the queries are split instead. The handle takes the HOST-pointer entry points
+ * (bivx_append*, bivx_build, bivx_count*, bivx_fill*, bivx_find_overlaps, bivx_any, bivx_get_*, bivx_get_stats), with
+ * the same ids and results as a single-device index; the `_dev` entry points address one device's memory and return
+ * BIVX_E_STATE for it. One host thread per device drives its shard. devices may name a device more than once.
+ * (Across PROCESSES — one rank per GPU — shard with the same LPT and gather with RCCL: binary_amd/sharding.py.) */
+int bivx_create_sharded(bivx_index **out, const int *devices, int ndev);
+int bivx_num_devices(const bivx_index *idx);                     /* 1 for a bivx_create handle */
+int bivx_device_of_chrom(const bivx_index *idx, uint32_t chrom); /* after build; -1: no interval on that chromosome */
+
 /* ---- build side -------------------------------------------------------------------------------
  * replaces: RbTree::insert_node(range) rb_tree.hpp:111-117 and insert_node(Args&&...) :145-149 — appends n
  * intervals; ids continue from bivx_size(). chrom may be NULL (all chrom 0). Host pointers. */

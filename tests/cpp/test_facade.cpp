@@ -140,6 +140,24 @@ static void host_side_cases() {
 }
 
 static void gpu_cases() {
+  {  // one tree over several devices (bivx_create_sharded; the test box has one card: {0, 0}): same answers
+    const std::array<int, 2> devs{0, 0};
+    IntervalTree<UIntIntervalNode> t{std::span<const int>(devs)};
+    t.insert_node(kFixture);
+    CHECK_EQ(t.size(), 10u);
+    CHECK_EQ(t.find_overlaps(7u, 25u).size(), 8u);
+    CHECK_EQ(t.find_overlaps(15u, 25u).size(), 5u);
+    auto one = t.find_overlap(22u, 25u);
+    CHECK(one.has_value() && one->low == 15u && one->high == 23u);
+    std::vector<UIntInterval> qs;
+    for (unsigned k = 0; k < 40; ++k) qs.emplace_back(k, k + 2);
+    auto b = t.find_overlaps_batch(qs);
+    IntervalTree<UIntIntervalNode> ref{};
+    ref.insert_node(kFixture);
+    auto rb = ref.find_overlaps_batch(qs);
+    CHECK(b.offsets == rb.offsets && b.ids == rb.ids);
+    CHECK_EQ(t.root()->key, 16u);
+  }
   {  // single insert (test_interval_tree.cpp:74-85)
     IntervalTree<UIntIntervalNode> t{};
     t.insert_node(16u, 21u);
