@@ -110,11 +110,9 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
   __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
   __shared__ uint2 s_cs[LDS_DESC ? kLdsChroms : 1];
   __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_last;  // this tile finished its prefix sweep last: it zeroes the workspace for the next call
   __shared__ uint32_t s_wsum[kFWaves];
   __shared__ uint64_t s_wsum64[kFWaves];  // the same in 64 bits, for tiles with very long hit lists
   __shared__ uint64_t s_base;
-  __shared__ uint64_t s_launch_total;  // unordered output, last tile only
   // ids of each query's first kKeepN hits (thread-private slots). Eight where LDS allows (1-2 % faster than four:
   // fewer ids are re-read in phase 2); the several-segment kernel spends that LDS on recorded windows instead.
   constexpr uint32_t kKeepN = MS ? 4 : 8;
@@ -131,7 +129,6 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
   const int wave = threadIdx.x >> 6;
 
   BIVX_STAMP(0);
-  if (threadIdx.x == 0) s_last = 0;
   // ordered output: tiles take tickets, so that every predecessor of a waiting tile is resident.
   // unordered output: tiles never wait for each other, any tile may be any block.
   if (threadIdx.x == 0)
@@ -241,21 +238,31 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
     // through the groups: the earlier tiles of this tile's group (one word per lane), then all earlier groups.
     const bool flat = gridDim.x <= kFlatTiles;
     const uint32_t g = tile >> 6, r = tile & 63u;
+    const uint64_t *words = flat ? status : group;
+    const uint32_t nwords = flat ? tile : g;
+    // The loads of the first round of words and of the in-group word leave together: a sweep that finds everything
+    // published costs one memory round trip, not one per level (the words are agent-scope atomics, which the
+    // compiler keeps in program order).
+    uint64_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t t = j * kWave + lane;
+      w[j] = t < nwords ? ld_status(&words[t]) : kStValid;
+    }
     uint64_t in_group = 0;
     if (!flat) {
       const uint64_t *mine = &status[(g << 6) + (uint32_t)lane];
       in_group = wave_total((uint32_t)lane < r ? wait_word(mine, ld_status(mine)) : 0ull);
       if (r == 63u && lane == 0) st_status(&group[g], kStValid | (in_group + total));
     }
-    const uint64_t *words = flat ? status : group;
-    const uint32_t nwords = flat ? tile : g;
     uint64_t sum = 0;
     for (uint32_t t0 = 0; t0 < nwords; t0 += 4 * kWave) {
-      uint64_t w[4];
+      if (t0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t t = t0 + j * kWave + lane;
-        w[j] = t < nwords ? ld_status(&words[t]) : kStValid;
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t t = t0 + j * kWave + lane;
+          w[j] = t < nwords ? ld_status(&words[t]) : kStValid;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -411,31 +418,33 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
   // atomic carries both: departures in the high bits, ids in the low kDoneShift bits), so the last tile knows the
   // launch total without reading a word other tiles are still adding to — no fence anywhere: an agent-scope fence
   // writes back and invalidates the XCD's whole L2 on this chip, which cost more than the prefix it replaced.
-  if (self_clean || U) {
-    if (threadIdx.x == 0) {
+  // Only wave 0 takes part: the other wavefronts leave as soon as their ids are out (a barrier here kept all
+  // sixteen for the departure atomic's round trip: 0.7-1.2 us per tile).
+  if ((self_clean || U) && wave == 0) {
+    uint32_t last = 0;
+    uint64_t launch_total = 0;
+    if (lane == 0) {
       if (U) {
         const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(ws + kWsDone),
                                                  (1ull << kDoneShift) | (unsigned long long)total);
         if ((old >> kDoneShift) == gridDim.x - 1) {
-          s_last = 1;
-          s_launch_total = (old & ((1ull << kDoneShift) - 1)) + total;  // ids reserved by this launch
+          last = 1;
+          launch_total = (old & ((1ull << kDoneShift) - 1)) + total;  // ids reserved by this launch
         }
       } else if (atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1) {
-        s_last = 1;
+        last = 1;
       }
     }
     BIVX_STAMP(9);   // departure counted
-    __syncthreads();
-    BIVX_STAMP(10);  // all sixteen wavefronts are through
-    if (s_last) {
+    if (__shfl(last, 0, kWave)) {
       if (!U)
-        for (uint32_t t = threadIdx.x; t < gridDim.x; t += kFThreads) {
+        for (uint32_t t = (uint32_t)lane; t < gridDim.x; t += kWave) {
           status[t] = 0;
           if (t < (gridDim.x + kWave - 1) / kWave) group[t] = 0;
         }
-      if (threadIdx.x == 0) {
+      if (lane == 0) {
         if (U) {  // running total over the call's launches; the reservation counter restarts after the last one
-          const uint64_t sum = ws[kWsCarry] + s_launch_total;
+          const uint64_t sum = ws[kWsCarry] + launch_total;
           *total_out = sum;
           ws[kWsCarry] = (flags & kFlagFinal) ? 0 : sum;
         }
