@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "query_device.h"
+#include "prefix_device.h"
 
 namespace bivx {
 namespace {
@@ -37,9 +38,6 @@ constexpr int kFWaves = kFThreads / kWave;
 // One query per thread. (More per thread was measured and did not pay: a wavefront here is latency-bound, and the
 // output staging below relies on the 64 lists of a wavefront being adjacent.)
 constexpr int kFTile = kFThreads;
-constexpr unsigned kFMaxTiles = 65536;                 // tiles per launch (ordered output)
-constexpr unsigned kFMaxGroups = kFMaxTiles / kWave;   // groups of 64 tiles
-constexpr unsigned kFlatTiles = 1024;                  // launches up to this many tiles sweep the tile words directly
 constexpr uint32_t kStage = 512;     // ids a wavefront lays out in LDS per round before streaming them out
 #ifndef BIVX_GATHER
 #define BIVX_GATHER 8
@@ -50,32 +48,6 @@ static_assert(kMaxRec * kLight <= kStage / 2, "a replayed list must fit half the
 #define BIVX_STAGE_MIN 128
 #endif
 constexpr uint32_t kStageMin = BIVX_STAGE_MIN;  // ... when it has at least this many (2 per lane); below that lanes store directly
-constexpr uint64_t kStValid = 1ull << 63;
-// workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
-// on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
-constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsNeedSort = 24, kWsStatus = 32;
-// ws[kWsNeedSort]: sequence number of the last launch that left lists for k_sort_hits to order (never cleared:
-// every launch carries a fresh number)
-constexpr uint32_t kDoneShift = 44;  // unordered output: ws[kWsDone] = departures << 44 | ids reserved by this launch
-// k_query_fused flags: index-owned workspace; last launch of the call; bits 8-15: log2 of the bound on a prefix
-// wait in ticks of the 100 MHz constant clock (0 = kWaitLog2Default)
-constexpr int kFlagSelfClean = 1, kFlagFinal = 2, kFlagWaitShift = 8;
-constexpr uint32_t kWaitLog2Default = 31;  // 2^31 x 10 ns = 21 s: only a device that stopped making progress gets there
-
-// A workgroup that cannot produce a valid result says so in the index's error block (host memory mapped into the
-// device: the host reads it without a copy after any synchronisation) instead of returning quietly; every
-// synchronising entry point and bivx_stream_status turn a raised word into BIVX_E_TIMEOUT (capi.hip).
-__device__ __forceinline__ void raise_error(uint32_t *err, uint32_t which) {
-  __hip_atomic_store(err + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_status(uint64_t *p, uint64_t w) {
-  __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Diagnostic build only (-DBIVX_STAMPS): per-tile wall-clock stamps (100 MHz constant counter) written to a
 // buffer no other code reads; the product build has no stamp.
 #ifdef BIVX_STAMPS
@@ -463,7 +435,8 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
 
 size_t fused_workspace_bytes(size_t q) {
   (void)q;
-  return ((size_t)kFMaxTiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t);
+  // header words, group words, tile words, then the pipelined kernel's list of tiles left for k_fill_tiles (u32 each)
+  return ((size_t)kFMaxTiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t) + (size_t)kFMaxTiles * sizeof(uint32_t);
 }
 
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
@@ -506,6 +479,12 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
     // ordered by k_sort_hits afterwards, whose stage is eight times larger.
     const bool sort_inside = sort_ids && !unordered && cap <= (uint64_t)kFusedSortMaxAvg * q;
+    // the common case (one segment per chromosome, no filter, index order, few ids per query) has a pipelined kernel
+    if (pipe_eligible(v, q, cap, sort_ids, unordered)) {
+      if (int rc = launch_query_pipe(v, d_qchrom, d_qlow, d_qhigh, q0, q1, tiles, d_offsets, d_hits, cap, ws, flags, s))
+        return rc;
+      continue;
+    }
     static std::atomic<uint32_t> launch_seq{1};
     uint32_t seq = launch_seq.fetch_add(1);
     if (seq == 0) seq = launch_seq.fetch_add(1);  // 0 is what a cleared workspace holds
