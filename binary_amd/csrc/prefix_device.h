@@ -119,6 +119,41 @@ __device__ __forceinline__ uint64_t tiles_before(const PrefixCtx &c, uint32_t ti
   return wave_total64(sum) + in_group;
 }
 
+// ---- the same without waiting (query_pipe.hip's service wavefront polls): false if a word is not published yet ---
+__device__ __forceinline__ bool try_sum_in_group(const PrefixCtx &c, uint32_t tile, int lane, uint64_t &sum) {
+  const uint32_t g = tile >> 6, r = tile & 63u;
+  const uint64_t w = (uint32_t)lane < r ? ld_status(&c.status[(g << 6) + (uint32_t)lane]) : kStValid;
+  if (!__all((w & kStValid) != 0)) return false;
+  sum = wave_total64(w & ~kStValid);
+  return true;
+}
+
+__device__ __forceinline__ bool try_tiles_before(const PrefixCtx &c, uint32_t tile, int lane, uint64_t &sum) {
+  const bool flat = c.ntiles <= kFlatTiles;
+  const uint64_t *words = flat ? c.status : c.group;
+  const uint32_t nwords = flat ? tile : tile >> 6;
+  uint64_t acc = 0;
+  for (uint32_t t0 = 0; t0 < nwords; t0 += 4 * kWave) {
+    uint64_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t t = t0 + j * kWave + lane;
+      w[j] = t < nwords ? ld_status(&words[t]) : kStValid;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ok = ok && (w[j] & kStValid) != 0;
+      acc += w[j] & ~kStValid;
+    }
+    if (!__all(ok)) return false;
+  }
+  uint64_t in_group = 0;
+  if (!flat && !try_sum_in_group(c, tile, lane, in_group)) return false;
+  sum = wave_total64(acc) + in_group;
+  return true;
+}
+
 }  // namespace
 }  // namespace bivx
 

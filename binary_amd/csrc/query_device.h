@@ -17,7 +17,7 @@ constexpr uint32_t kLight = 64;      // window slots a lane reads by itself; lon
 #endif
 constexpr uint32_t kTrim = BIVX_TRIM;  // wavefront windows longer than this are first trimmed by a 64-ary search
 constexpr uint32_t kRows = 4;        // rows of 64 slots (and their ids) the wavefront-cooperative path keeps in flight
-constexpr uint32_t kSlabSlots = 256;  // candidate slots a wavefront stages through LDS when its 64 windows are neighbours
+constexpr uint32_t kSlabSlots = 256;  // candidate slots a wavefront stages through LDS when its 64 windows are neighbours (8 keep slots per lane; 128 with 4)
 constexpr uint32_t kSlabMinLanes = 32;  // ... and at least this many of its lanes' windows fit the slab
 constexpr uint32_t kLdsSegs = 128;   // descriptors staged in LDS (4 KiB) ...
 constexpr uint32_t kLdsChroms = 512; // ... with the chromosomes' segment ranges (4 KiB); larger indexes read them from global
@@ -343,11 +343,11 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
     if (SLAB && M == Mode::Count) {
       const bool cand = nonempty && !heavy && packed;
       lbase = __builtin_amdgcn_readfirstlane(wave_min(cand ? (w.a & ~1u) : 0xFFFFFFFFu));
-      in_slab = cand && w.b - lbase <= kSlabSlots;
+      in_slab = cand && w.b - lbase <= KEEP * (kWave / 2);  // the slab is the 64 lanes' keep slots: KEEP * 32 records
       slab_on = (uint32_t)__popcll(__ballot(in_slab)) >= kSlabMinLanes;
       if (slab_on) {
         const uint32_t bmax = __builtin_amdgcn_readfirstlane(wave_max(in_slab ? w.b : 0u));
-        const uint32_t npairs = (bmax - lbase + 1) >> 1;  // <= kSlabSlots / 2; rec[] carries two spare slots
+        const uint32_t npairs = (bmax - lbase + 1) >> 1;  // fits the slab; rec[] carries two spare slots
         const uint4 *src = reinterpret_cast<const uint4 *>(v.rec) + (lbase >> 1);
         for (uint32_t i = (uint32_t)lane; i < npairs; i += kWave) slab[i] = src[i];
         wave_sync_lds();

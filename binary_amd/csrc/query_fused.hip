@@ -456,13 +456,21 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     const long v = std::atol(e);
     if (v >= 1 && v < (long)max_tiles) max_tiles = (unsigned)v;
   }
-  const size_t per_launch = (size_t)max_tiles * kFTile;
+  // the common case (one segment per chromosome, no filter, index order, few ids per query) has a pipelined kernel
+  // with tiles of its own size
+  const bool use_pipe = pipe_eligible(v, q, cap, sort_ids, unordered);
+  size_t per_launch = (size_t)max_tiles * kFTile;
+  if (use_pipe) {
+    const size_t pp = pipe_queries_per_launch() / kFMaxTiles * max_tiles;
+    per_launch = pp;
+  }
   // caller's workspace: zeroed in front of every launch (ordered output), or once per call (unordered output:
   // the running total lives in it across the call's launches)
   if (!self_clean && unordered) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));
   for (size_t q0 = 0; q0 < q; q0 += per_launch) {
     const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
-    const unsigned tiles = (unsigned)((q1 - q0 + kFTile - 1) / kFTile);
+    const size_t tile_q = use_pipe ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
+    const unsigned tiles = (unsigned)((q1 - q0 + tile_q - 1) / tile_q);
     if (!self_clean && !unordered)
       BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
     const dim3 grid(tiles), block(kFThreads);
@@ -479,9 +487,8 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
     // ordered by k_sort_hits afterwards, whose stage is eight times larger.
     const bool sort_inside = sort_ids && !unordered && cap <= (uint64_t)kFusedSortMaxAvg * q;
-    // the common case (one segment per chromosome, no filter, index order, few ids per query) has a pipelined kernel
-    if (pipe_eligible(v, q, cap, sort_ids, unordered)) {
-      if (int rc = launch_query_pipe(v, d_qchrom, d_qlow, d_qhigh, q0, q1, tiles, d_offsets, d_hits, cap, ws, flags, s))
+    if (use_pipe) {
+      if (int rc = launch_query_pipe(v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, flags, s))
         return rc;
       continue;
     }

@@ -1,24 +1,31 @@
 // query_pipe.hip — the pipelined form of the single-pass query kernel (gfx950, wave64), for the common case:
-// one segment per chromosome, no fused filter, canonical CSR in index order, few ids per query. Same protocol and
-// same output, bit for bit, as k_query_fused (query_fused.hip), which keeps every other case.
+// one segment per chromosome, no fused filter, canonical CSR in index order, few ids per query. Same protocol between
+// workgroups and the same output, bit for bit, as k_query_fused (query_fused.hip), which keeps every other case.
 //
-// Why: a tile of k_query_fused lives ~22 us (config 3, generation order) of which ~8.5 us are the counting; the rest
-// is the ticket, the barrier skew of sixteen wavefronts, the sweep over the earlier tiles' totals and the way out
-//  — and a CU holds two tiles, so throughput is 2048 queries per tile lifetime. Here workgroups
-// are PERSISTENT (two per CU) and a tile's output is DEFERRED by one iteration:
-//   iteration i:  count tile N (masks; first ids in the keep slots / slab) -> barrier A -> wave 0: publish N's total,
-//                 draw the next ticket, sum the totals before tile O = the tile of iteration i-1 (published an
-//                 iteration ago: its predecessors are through, the sweep finds every word valid) -> barrier B ->
-//                 every wavefront: prefetch the next tile's queries; write O's offsets and stream O's ids out of the
-//                 stage; lay N's ids out in the stage, back to back as they will sit in the output.
-// What a tile carries across the iteration is its stage (the 2 KiB per wavefront that k_query_fused uses for output
-// staging) and ONE register per lane (list offset | count); the keep slots / slab are free again for the next tile.
-// The sweep's latency, the store latency and a good part of the barrier skew overlap the next tile's counting.
-// A tile with a wavefront that cannot stage (more than kStage ids, a wavefront-cooperative window) gets its counts
-// and offsets here — the prefix chain needs them — and is put on a list; k_fill_tiles, launched behind this kernel,
-// enumerates the listed tiles' ids into place (it finds the list empty on ordinary data and returns).
-// Tickets are drawn a few microseconds ahead (after barrier A), not a whole tile ahead: a ticket held by a busy
-// workgroup delays that tile's published total and every later sweep waits for it (measured: 0.49 -> 0.84 ms).
+// Why: a tile of k_query_fused lives ~22 us (config 3, generation order) of which 7-8 us are the counting; the rest is
+// the ticket, the barrier skew of sixteen wavefronts, the sweep over the earlier tiles' totals and the way out
+//  — and a CU holds two tiles, so throughput is 2048 queries per tile lifetime.
+//
+// Here workgroups are PERSISTENT (two per CU), their wavefronts are SPECIALISED and they never meet at a barrier:
+//   * fifteen WORKER wavefronts each own 64 consecutive queries of every tile the workgroup draws (a tile is 960
+//     queries). A worker counts its slice of tile N (masks; first ids in its keep slots / slab), reports its total,
+//     then writes the offsets and streams the ids of its slice of the PREVIOUS tile O out of its stage (they were laid
+//     out there an iteration ago, exactly as they sit in the output), lays N's ids out in the stage, and goes on to the
+//     next tile. What a slice carries across the iteration is the stage (2 KiB) and ONE register per lane.
+//   * one SERVICE wavefront draws the tickets (one tile ahead, so that the workers can fetch the next tile's queries
+//     early), waits — in LDS — for the fifteen totals of a tile, publishes the tile's total (one 8-byte agent-scope
+//     word), sums the totals of all earlier tiles (the wide sweep of query_fused.hip, the only place that waits for
+//     other workgroups) and hands the tile's first output position and the workers' bases back through LDS.
+// A worker only waits for words of its own workgroup that were written an iteration earlier, so the ticket's round
+// trip, the barrier skew, the sweep's latency and the store latency all overlap counting. The words live in a ring of
+// kRing tile slots in LDS; a slot is recycled when all fifteen workers have flushed the tile that used it.
+// A slice that cannot be staged (more than kPStage ids, a wavefront-cooperative window) gets its counts and offsets
+// here — the prefix chain needs them — and is put on a list; k_fill_slices, launched behind this kernel, enumerates
+// the listed slices' ids into place (it finds the list empty on ordinary data and returns).
+// Deadlock: a worker waits for its own service wavefront only; a service wavefront waits for workers of its own
+// workgroup (which never wait for other workgroups) and for tiles with SMALLER tickets, all drawn by resident
+// workgroups; the smallest unpublished tile can therefore always be finished. Waits on other workgroups are bounded
+// by wall time and an expired one fails the call (prefix_device.h).
 #include <cstdlib>
 
 #include "prefix_device.h"
@@ -29,11 +36,14 @@ namespace {
 
 constexpr int kPThreads = 1024;
 constexpr int kPWaves = kPThreads / kWave;
-constexpr uint32_t kPStage = 512;   // ids per wavefront stage
+constexpr int kWorkers = kPWaves - 1;          // wavefront kWorkers is the service wavefront
+constexpr uint32_t kPTile = kWorkers * kWave;  // 960 queries
+constexpr uint32_t kRing = 8;                  // tile slots in LDS
+constexpr uint32_t kPStage = 320;   // ids per wavefront stage (there are two: a slice waits two iterations for its base)
 constexpr uint32_t kPKeep = 8;      // ids kept per query while counting (a wavefront's 64 x 8 slots are its slab too)
 constexpr uint32_t kPGather = 4;    // ids a lane re-reads per step when more than kPKeep were found outside the slab
 
-// Diagnostic build only (-DBIVX_STAMPS): per-tile wall-clock stamps, written to a buffer no other code reads.
+// Diagnostic build only (-DBIVX_STAMPS): wall-clock stamps of worker 0, written to a buffer no other code reads.
 #ifdef BIVX_STAMPS
 constexpr unsigned kPStampTiles = 1024, kPStampSlots = 8;
 __device__ unsigned long long g_pstamps[kPStampTiles * kPStampSlots];
@@ -58,7 +68,7 @@ struct PipeArgs {
 // where they are used: a persistent loop otherwise keeps all ~50 scalar registers of pointers and sizes alive across
 // every phase, and with 80 SGPRs per wavefront (what eight wavefronts per SIMD leave) the compiler answers with a
 // hundred scalar spills that push the vector registers into scratch. The empty asm makes the segment's address
-// opaque at every phase boundary, so nothing read through it can be held across one.
+// opaque wherever it is used, so nothing read through it is held longer than its use.
 struct KernArgs {
   IndexView v;
   PipeArgs a;
@@ -69,308 +79,416 @@ __device__ __forceinline__ kargs_t fresh(kargs_t p) {
   return p;
 }
 
+// One tile's words in LDS. `gen_*` carry the workgroup's iteration number + 1 of the tile the words belong to, so
+// nothing has to be cleared between uses except the two counters, which the service wavefront resets while nobody
+// looks (before it hands the slot's new ticket out).
+struct TileSlot {
+  uint32_t tile;        // the ticket (service -> workers)
+  uint32_t gen_ticket;  // iteration + 1 once `tile` is valid
+  uint32_t arrived;     // workers that have reported their slice's total
+  uint32_t flushed;     // workers that are through with the tile (its slot may be recycled at kWorkers)
+  uint32_t gen_base;    // iteration + 1 once `base` and `wbase` are valid
+  uint32_t pad;
+  uint64_t base;              // first output position of the tile
+  uint64_t wsum[kWorkers];    // ids of each slice (workers -> service)
+  uint64_t wbase[kWorkers];   // ids of the tile's earlier slices (service -> workers)
+};
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store(uint32_t *p, uint32_t x) {
+  __hip_atomic_store(p, x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// (uniform per wavefront: every lane polls the same word)
+__device__ __forceinline__ void lds_wait_eq(const uint32_t *p, uint32_t x) {
+  while (lds_load(p) != x) __builtin_amdgcn_s_sleep(1);
+}
+
 __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, PipeArgs a_in) {
   (void)v_in;
   (void)a_in;
   kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
 #define A(f) (fresh(ka)->a.f)
-  // a view of the index made of freshly read words (only the fields a phase uses are ever loaded)
-  auto view_now = [&]() {
-    kargs_t p = fresh(ka);
-    IndexView w;
-    w.se = p->v.se;
-    w.rec = p->v.rec;
-    w.id = p->v.id;
-    w.table = p->v.table;
-    w.seg = p->v.seg;
-    w.chrom_rng = p->v.chrom_rng;
-    w.nchrom = p->v.nchrom;
-    w.nseg = p->v.nseg;
-    w.max_segs = 1;
-    w.flt_kind = BIVX_FILTER_NONE;
-    w.flt_dist = 0;
-    w.flt_strand = 0;
-    w.flt_qaux = nullptr;
-    w.flt_iaux = nullptr;
-    w.err = p->v.err;
-    return w;
-  };
-  auto prefix_now = [&]() {
-    kargs_t p = fresh(ka);
-    PrefixCtx c;
-    c.group = p->a.ws + kWsStatus;
-    c.status = c.group + kFMaxGroups;
-    c.ntiles = p->a.ntiles;
-    const uint32_t wl = ((uint32_t)p->a.flags >> kFlagWaitShift) & 0xFFu;
-    c.wait_ticks = 1ull << (wl ? wl : kWaitLog2Default);
-    c.err = p->v.err;
-    return c;
-  };
   __shared__ SegDesc s_seg[kLdsSegs];
   __shared__ uint2 s_cs[kLdsChroms];
-  // the words the wavefronts hand each other are double-buffered by the parity of the iteration: a wavefront that
-  // is through with an iteration walks into the next while slower ones still finish; the two barriers of an
-  // iteration are the only places where the sixteen wait for each other
-  __shared__ uint32_t s_tile[2];
-  __shared__ uint32_t s_wsum[2][kPWaves];
-  __shared__ uint64_t s_w64[kPWaves];               // wavefront totals of a listed tile, in 64 bits
-  __shared__ uint64_t s_base[2];                    // first output position of the pending tile [0], of a listed new tile [1]
-  __shared__ uint4 s_keep[kPThreads * (kPKeep / 4)];   // keep slots / slabs of the tile being counted
-  __shared__ uint32_t s_stage[kPWaves][kPStage];       // ids of the pending tile, laid out as in the output
+  __shared__ TileSlot s_slot[kRing];
+  __shared__ uint4 s_keep[kWorkers * kWave * (kPKeep / 4)];   // keep slots / slabs of the slice being counted
+  __shared__ uint32_t s_stage[kWorkers][2][kPStage];          // ids of the two pending slices, laid out as in the output
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
-  if (threadIdx.x == 0) s_tile[0] = atomicAdd(reinterpret_cast<unsigned int *>(A(ws) + kWsTicket), 1u);
-  const SegDesc *segs;
-  const uint2 *cs;
-  {
-    const IndexView v0 = view_now();
-    stage_descriptors<true>(v0, s_seg, s_cs, segs, cs);
-  }
-  __syncthreads();
-
-  uint32_t *const kept = reinterpret_cast<uint32_t *>(&s_keep[threadIdx.x * (kPKeep / 4)]);
-  uint4 *const slab = &s_keep[(threadIdx.x & ~(kWave - 1)) * (kPKeep / 4)];
-  uint32_t *const stage = s_stage[wave];
-
-  // the pending tile of this workgroup: counted and published, its ids in the stage, output deferred
-  bool have_old = false;
-  uint32_t o_tile = 0, o_wbase = 0, o_wtotal = 0, o_state = 0;
-  auto flush_old = [&](uint64_t base) {
+  {  // descriptors and the ring, once per workgroup
     kargs_t p = fresh(ka);
-    const size_t q_end = p->a.q_end;
-    const size_t q = p->a.q_begin + (size_t)o_tile * kPThreads + threadIdx.x;
-    const uint64_t wpos0 = base + o_wbase;
-    if (q < q_end) {
-      uint64_t *off = p->a.offsets;
-      off[q] = wpos0 + (o_state >> 16);
-      if (q == q_end - 1) off[q_end] = wpos0 + (o_state >> 16) + (o_state & 0xFFFFu);
+    const uint4 *src = reinterpret_cast<const uint4 *>(p->v.seg);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_seg);
+    const uint32_t nseg2 = p->v.nseg * 2, nchrom = p->v.nchrom;
+    for (uint32_t t = threadIdx.x; t < nseg2; t += kPThreads) dst[t] = src[t];
+    const uint2 *rng = p->v.chrom_rng;
+    for (uint32_t t = threadIdx.x; t < nchrom; t += kPThreads) s_cs[t] = rng[t];
+    if (threadIdx.x < kRing) {
+      s_slot[threadIdx.x].gen_ticket = 0;
+      s_slot[threadIdx.x].gen_base = 0;
+      s_slot[threadIdx.x].arrived = 0;
+      s_slot[threadIdx.x].flushed = 0;
     }
-    const uint64_t cap = p->a.cap;
-    if (cap != 0) {
-      uint32_t *hits = p->a.hits;
-      for (uint32_t i = lane; i < o_wtotal; i += kWave) {
-        const uint64_t pos = wpos0 + i;
-        if (pos < cap) hits[pos] = stage[i];
+  }
+  __syncthreads();  // the only barrier of the kernel
+  const SegDesc *const segs = s_seg;
+  const uint2 *const cs = s_cs;
+
+  if (wave == kWorkers) {
+    // ================================ the service wavefront ================================================
+    PrefixCtx pc;
+    {
+      kargs_t p = fresh(ka);
+      pc.group = p->a.ws + kWsStatus;
+      pc.status = pc.group + kFMaxGroups;
+      pc.ntiles = p->a.ntiles;
+      const uint32_t wl = ((uint32_t)p->a.flags >> kFlagWaitShift) & 0xFFu;
+      pc.wait_ticks = 1ull << (wl ? wl : kWaitLog2Default);
+      pc.err = p->v.err;
+    }
+    // A polled state machine over the workgroup's tiles, in the order they were drawn (iteration numbers):
+    //   drawn:     tickets handed out so far. Ticket k+1 is drawn when the first worker has reported on tile k (its
+    //              queries can then be fetched while the stragglers finish), never earlier: a ticket held by a busy
+    //              workgroup delays that tile's published total, and every later tile's sweep waits for it.
+    //   published: tiles whose total is out (needs the fifteen totals);   grouped: ... whose group word, if it is the
+    //   64th tile of a group, is out (needs the group's earlier tiles);   swept: ... whose first output position the
+    //   workers have (needs every earlier tile of the launch). None of the three waits inside: a sweep that finds a
+    //   word missing is simply tried again on the next pass, so one slow predecessor never holds a ticket back.
+    uint32_t drawn = 0, published = 0, grouped = 0, swept = 0;
+    uint32_t last_tile = 0;   // ticket of the newest drawn tile
+    bool drawing = true;      // no ticket beyond the batch yet
+    uint64_t stuck_since = 0; // when the oldest unswept tile's sweep was first found blocked
+    const bool flat = pc.ntiles <= kFlatTiles;
+    for (;;) {
+      bool progress = false;
+      // ---- a ticket ----
+      if (drawing && drawn - swept < kRing) {
+        bool want = drawn == 0;
+#ifdef BIVX_TICKET_EARLY   // experiment: a whole counting phase ahead (when every worker has begun the tile before)
+        if (!want) want = drawn == 1 || lds_load(&s_slot[(drawn - 2) % kRing].arrived) == (uint32_t)kWorkers;
+#else
+        if (!want) want = lds_load(&s_slot[(drawn - 1) % kRing].arrived) != 0;
+#endif
+        TileSlot &sl = s_slot[drawn % kRing];
+        // (the slot's last user was iteration drawn - kRing: swept, but every worker must also be through with it)
+        if (want && (drawn < kRing || lds_load(&sl.flushed) == (uint32_t)kWorkers)) {
+          uint32_t tile = 0;
+          if (lane == 0) {
+            tile = atomicAdd(reinterpret_cast<unsigned int *>(A(ws) + kWsTicket), 1u);
+            sl.arrived = 0;
+            sl.flushed = 0;
+            sl.tile = tile;
+            lds_store(&sl.gen_ticket, drawn + 1);
+          }
+          last_tile = __builtin_amdgcn_readfirstlane(tile);
+          // Every workgroup draws exactly one ticket beyond the batch, so none can reach ntiles + gridDim.x unless
+          // the counter was not zero when the launch began (a launch that died half-way, a caller workspace that was
+          // not cleared): then tiles were skipped and nothing this launch wrote can be trusted. Say so.
+          if (last_tile >= pc.ntiles + gridDim.x && lane == 0) raise_error(pc.err, kErrWorkspace);
+          if (last_tile >= pc.ntiles) drawing = false;  // the workers see it, flush what is pending and leave
+          ++drawn;
+          progress = true;
+        }
+      }
+      const uint32_t real = drawing ? drawn : drawn - 1;  // tiles of the batch among the drawn ones
+      // ---- publish ----
+      if (published < real) {
+        TileSlot &ps = s_slot[published % kRing];
+        if (lds_load(&ps.arrived) == (uint32_t)kWorkers) {
+          const uint64_t mine = lane < kWorkers ? ps.wsum[lane] : 0ull;
+          uint64_t incl = mine;
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) {
+            const uint64_t o = __shfl_up((unsigned long long)incl, d, kWave);
+            if (lane >= d) incl += o;
+          }
+          if (lane < kWorkers) ps.wbase[lane] = incl - mine;
+          const uint64_t total = __shfl((unsigned long long)incl, kWorkers - 1, kWave);
+          if (lane == 0) {
+            ps.base = total;  // parked here until the sweep replaces it with the tile's first position
+            st_status(&pc.status[ps.tile], kStValid | total);
+          }
+          ++published;
+          progress = true;
+        }
+      }
+      // ---- the group word of a group's 64th tile ----
+      if (grouped < published) {
+        TileSlot &gs = s_slot[grouped % kRing];
+        const uint32_t t = gs.tile;
+        if (flat || (t & 63u) != 63u) {
+          ++grouped;
+          progress = true;
+        } else {
+          uint64_t in_group = 0;
+          if (try_sum_in_group(pc, t, lane, in_group)) {
+            if (lane == 0) st_status(&pc.group[t >> 6], kStValid | (in_group + gs.base));
+            ++grouped;
+            progress = true;
+          }
+        }
+      }
+      // ---- sweep ----
+      if (swept < grouped) {
+        TileSlot &ss = s_slot[swept % kRing];
+        uint64_t sum = 0;
+        bool ok = try_tiles_before(pc, ss.tile, lane, sum);
+        if (!ok) {
+          // bounded by wall time: a device that stopped making progress fails the call instead of hanging it
+          const uint64_t now = __builtin_amdgcn_s_memrealtime();
+          if (stuck_since == 0) stuck_since = now;
+          else if (now - stuck_since > pc.wait_ticks) {
+            if (lane == 0) raise_error(pc.err, kErrTimeout);
+            ok = true;  // go on with a wrong prefix; no entry point lets the call pass as success
+          }
+        }
+        if (ok) {
+          if (lane == 0) {
+            const size_t qb = A(q_begin);
+            ss.base = sum + (qb ? A(offsets)[qb] : 0ull);
+          }
+          lds_store(&ss.gen_base, swept + 1);  // (every lane stores the same word, after lane 0's base)
+          ++swept;
+          stuck_since = 0;
+          progress = true;
+        }
+      }
+      if (!drawing && swept == drawn - 1) break;
+      if (!progress) __builtin_amdgcn_s_sleep(2);
+    }
+    // self-cleaning workspace: every service wavefront bumps `done` when its sweeps are over and its last ticket is
+    // drawn; the one that sees gridDim.x - 1 knows nobody touches the words any more and zeroes them for the next
+    // launch (the list of slices for k_fill_slices stays: that kernel clears its count).
+    if (A(flags) & kFlagSelfClean) {
+      uint64_t *ws = A(ws);
+      uint32_t last = 0;
+      if (lane == 0) last = atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1 ? 1u : 0u;
+      if (__shfl(last, 0, kWave)) {
+        for (uint32_t t = (uint32_t)lane; t < pc.ntiles; t += kWave) {
+          pc.status[t] = 0;
+          if (t < (pc.ntiles + kWave - 1) / kWave) pc.group[t] = 0;
+        }
+        if (lane == 0) {
+          ws[kWsTicket] = 0;
+          ws[kWsDone] = 0;
+        }
       }
     }
-  };
+    return;
+  }
+
+  // ==================================== a worker wavefront ===================================================
+  uint32_t *const kept = reinterpret_cast<uint32_t *>(&s_keep[threadIdx.x * (kPKeep / 4)]);
+  uint4 *const slab = &s_keep[(threadIdx.x & ~(kWave - 1)) * (kPKeep / 4)];
+
   auto query_of = [&](uint32_t t) {
     kargs_t p = fresh(ka);
-    const size_t q = p->a.q_begin + (size_t)t * kPThreads + threadIdx.x;
+    const size_t q = p->a.q_begin + (size_t)t * kPTile + threadIdx.x;
     IndexView w;  // load_query reads nchrom only (no filter)
     w.nchrom = p->v.nchrom;
     w.flt_qaux = nullptr;
     return load_query<false>(w, cs, p->a.qchrom, p->a.qlow, p->a.qhigh, q, t < p->a.ntiles && q < p->a.q_end);
   };
 
-  // the first tile's queries; later tiles' are fetched an iteration ahead, behind barrier B
-  uint32_t tile = __builtin_amdgcn_readfirstlane(s_tile[0]);
+  // The two pending slices: counted and reported, their ids in a stage each (or, unstaged, their counts), output
+  // deferred by TWO iterations — the sweep for a tile has two counting phases to find its predecessors published
+  // (with one, a workgroup that falls behind stalls everybody after it in ticket order: measured 4.5 us median,
+  // 14 us p90 of waiting per iteration). `a` is the younger.
+  struct Pending {
+    bool have, staged;
+    uint32_t tile, wtotal, state;
+  };
+  Pending pa{false, false, 0u, 0u, 0u}, pb{false, false, 0u, 0u, 0u};
+  // writes the offsets of a pending slice and streams its ids; `j` is the iteration it was counted in
+  auto flush = [&](const Pending &pd, uint32_t j) {
+    TileSlot &os = s_slot[j % kRing];
+    uint32_t *const stage = s_stage[wave][j & 1u];
+    lds_wait_eq(&os.gen_base, j + 1);
+    const uint64_t wpos0 = os.base + os.wbase[wave];
+    kargs_t p = fresh(ka);
+    const size_t q_end = p->a.q_end;
+    const size_t q = p->a.q_begin + (size_t)pd.tile * kPTile + threadIdx.x;
+    uint64_t *off = p->a.offsets;
+    if (pd.staged) {
+      if (q < q_end) {
+        off[q] = wpos0 + (pd.state >> 16);
+        if (q == q_end - 1) off[q_end] = wpos0 + (pd.state >> 16) + (pd.state & 0xFFFFu);
+      }
+      const uint64_t cap = p->a.cap;
+      if (cap != 0) {
+        uint32_t *hits = p->a.hits;
+        for (uint32_t i = lane; i < pd.wtotal; i += kWave) {
+          const uint64_t pos = wpos0 + i;
+          if (pos < cap) hits[pos] = stage[i];
+        }
+      }
+    } else {
+      // an unstaged slice kept (list offset, count) per lane in its stage; its ids are k_fill_slices' business
+      const uint64_t lp = (uint64_t)stage[3 * lane] | (uint64_t)stage[3 * lane + 1] << 32;
+      const uint32_t c = stage[3 * lane + 2];
+      if (q < q_end) {
+        off[q] = wpos0 + lp;
+        if (q == q_end - 1) off[q_end] = wpos0 + lp + c;
+      }
+      if (lane == 0) {
+        uint64_t *ws = p->a.ws;
+        uint32_t *todo = reinterpret_cast<uint32_t *>(ws + kWsStatus + kFMaxGroups + kFMaxTiles);
+        todo[atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTodo), 1u)] = pd.tile * 16u + (uint32_t)wave;
+      }
+    }
+    wave_sync_lds();  // the stage may be refilled now
+    if (lane == 0) __hip_atomic_fetch_add(&os.flushed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  lds_wait_eq(&s_slot[0].gen_ticket, 1u);
+  uint32_t tile = __builtin_amdgcn_readfirstlane(s_slot[0].tile);
   Query qy = query_of(tile);
 
-  for (uint32_t par = 0;; par ^= 1u) {
-    if (tile >= A(ntiles)) {
-      // Every workgroup draws exactly one ticket beyond the batch, so none can reach ntiles + gridDim.x unless the
-      // counter was not zero when the launch began (a launch that died half-way, a caller workspace that was not
-      // cleared): then tiles were skipped and nothing this launch wrote can be trusted. Say so.
-      if (tile >= A(ntiles) + gridDim.x && threadIdx.x == 0) raise_error(fresh(ka)->v.err, kErrWorkspace);
-      if (have_old) {  // drain
-        if (wave == 0) {
-          const PrefixCtx pc = prefix_now();
-          const uint64_t sum = tiles_before(pc, o_tile, lane);
-          if (lane == 0) s_base[0] = sum + (A(q_begin) ? A(offsets)[A(q_begin)] : 0ull);
-        }
-        __syncthreads();
-        flush_old(s_base[0]);
-      }
-      break;
-    }
-
-    PSTAMP(tile, 0);
-    // ---- count the new tile ---------------------------------------------------------------------------------
+  for (uint32_t it = 0;; ++it) {
+    const bool live = tile < A(ntiles);
     Replay rp;
-    uint32_t cnt;
-    {
-      const IndexView v1 = view_now();
-      cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, true>(v1, segs, qy, nullptr, 0, 0, &rp, kept,
-                                                                         nullptr, slab);
-    }
-    uint32_t incl = cnt;
+    uint32_t cnt = 0, loff = 0, wtotal = 0;
+    bool staged = false, no_ids = false;
+    uint64_t lpos64 = 0;
+    if (live) {
+      PSTAMP(tile, 0);
+      // ---- count the slice of the new tile ------------------------------------------------------------------
+      {
+        kargs_t p = fresh(ka);
+        IndexView v1;
+        v1.se = p->v.se;
+        v1.rec = p->v.rec;
+        v1.id = p->v.id;
+        v1.table = p->v.table;
+        v1.seg = nullptr;
+        v1.chrom_rng = nullptr;
+        v1.nchrom = 0;
+        v1.nseg = 0;
+        v1.max_segs = 1;
+        v1.flt_kind = BIVX_FILTER_NONE;
+        v1.flt_dist = 0;
+        v1.flt_strand = 0;
+        v1.flt_qaux = nullptr;
+        v1.flt_iaux = nullptr;
+        v1.err = nullptr;
+        cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, true>(v1, segs, qy, nullptr, 0, 0, &rp, kept,
+                                                                           nullptr, slab);
+      }
+      uint32_t incl = cnt;
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d, kWave);
-      if (lane >= d) incl += o;
-    }
-    const uint32_t loff = incl - cnt;
-    // 2^22 hits in one lane would overflow the 32-bit tile sums: such a tile is counted in 64 bits below
-    const bool huge = cnt >= (1u << 22);
-    const uint32_t wtotal = __builtin_amdgcn_readfirstlane(__shfl(incl, kWave - 1, kWave));
-    // (uniform per wavefront; a pure count has no ids to lay out, only the packed state must fit)
-    const bool no_ids = A(cap) == 0;
-    const bool staged = no_ids ? !__any(huge) && wtotal < 65536u : !__any(huge || !rp.ok) && wtotal <= kPStage;
-    if (lane == kWave - 1) s_wsum[par][wave] = incl;
-    PSTAMP(tile, 1);
-    const bool listed = __syncthreads_or(!staged) != 0;  // (barrier A)
-    PSTAMP(tile, 2);
-    uint64_t total = 0, wbase = 0;
-    if (!listed) {
-      uint32_t wb = 0, t32 = 0;
-#pragma unroll
-      for (int w = 0; w < kPWaves; ++w) {
-        const uint32_t x = s_wsum[par][w];
-        if (w < wave) wb += x;
-        t32 += x;
+      for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += o;
       }
-      total = t32;
-      wbase = wb;
-    } else {  // rare: the sixteen wavefront totals again, in 64 bits
-      const uint64_t wt = wave_total64(cnt);
-      if (lane == 0) s_w64[wave] = wt;
-      __syncthreads();
-      for (int w = 0; w < kPWaves; ++w) {
-        const uint64_t x = s_w64[w];
-        if (w < wave) wbase += x;
-        total += x;
-      }
-    }
-
-    // ---- publish, next ticket, sweeps ------------------------------------------------------------------------
-    if (wave == 0) {
-      const PrefixCtx pc = prefix_now();
-      uint64_t *ws = A(ws);
-      uint32_t next_tile = 0;
-      if (lane == 0) next_tile = atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTicket), 1u);
-      publish_tile(pc, tile, total, lane);
-      const size_t qb = A(q_begin);
-      const uint64_t carry = qb ? A(offsets)[qb] : 0ull;
-      if (have_old) {
-        const uint64_t sum = tiles_before(pc, o_tile, lane);
-        if (lane == 0) s_base[0] = sum + carry;
-      }
-      if (listed) {
-        const uint64_t sum = tiles_before(pc, tile, lane);
-        if (lane == 0) {
-          s_base[1] = sum + carry;
-          uint32_t *todo = reinterpret_cast<uint32_t *>(pc.status + kFMaxTiles);
-          todo[atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTodo), 1u)] = tile;
-        }
-      }
-      if (lane == 0) s_tile[par ^ 1u] = next_tile;
-      PSTAMP(tile, 3);
-    }
-    __syncthreads();  // (barrier B)
-    PSTAMP(tile, 4);
-
-    // ---- the next tile's queries leave now; the pending tile goes out; the new tile's ids are laid out -----------
-    const uint32_t ntile = __builtin_amdgcn_readfirstlane(s_tile[par ^ 1u]);
-    const Query nqy = query_of(ntile);
-    if (have_old) flush_old(s_base[0]);
-    PSTAMP(tile, 5);
-    have_old = !listed;
-    if (listed) {
-      // counts and offsets only; k_fill_tiles writes the ids
-      uint64_t lpos = loff;
-      if (__any(huge)) {  // a wavefront with such a lane: its list offsets need 64 bits too
+      loff = incl - cnt;
+      // (2^22 hits in one lane would overflow the 32-bit scan: such a slice is never staged and is counted in 64 bits)
+      const bool huge = __any(cnt >= (1u << 22));
+      wtotal = __builtin_amdgcn_readfirstlane(__shfl(incl, kWave - 1, kWave));
+      no_ids = A(cap) == 0;
+      staged = !huge && (no_ids ? wtotal < 65536u : !__any(!rp.ok) && wtotal <= kPStage);
+      uint64_t wt64 = wtotal;
+      lpos64 = loff;
+      if (huge) {
         uint64_t i64 = cnt;
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
           const uint64_t o = __shfl_up((unsigned long long)i64, d, kWave);
           if (lane >= d) i64 += o;
         }
-        lpos = i64 - cnt;
+        lpos64 = i64 - cnt;
+        wt64 = __shfl((unsigned long long)i64, kWave - 1, kWave);
       }
-      const uint64_t pos = s_base[1] + wbase + lpos;
-      kargs_t p = fresh(ka);
-      const size_t q_end = p->a.q_end;
-      const size_t q = p->a.q_begin + (size_t)tile * kPThreads + threadIdx.x;
-      if (q < q_end) {
-        uint64_t *off = p->a.offsets;
-        off[q] = pos;
-        if (q == q_end - 1) off[q_end] = pos + cnt;
+      // report the slice's total (the service wavefront publishes the tile when all fifteen are in)
+      TileSlot &sl = s_slot[it % kRing];
+      if (lane == 0) {
+        sl.wsum[wave] = wt64;
+        __hip_atomic_fetch_add(&sl.arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-    } else {
-      o_tile = tile;
-      o_wbase = (uint32_t)wbase;
-      o_wtotal = wtotal;
-      o_state = (loff << 16) | cnt;
-      if (!no_ids) {
-        wave_sync_lds();  // the stage was read by flush_old just above
-        if (cnt) {
-          uint64_t mrem = rp.mask;
-          if (rp.lds) {  // everything is in the wavefront's slab
-            const uint2 *s2 = reinterpret_cast<const uint2 *>(slab) + (rp.al - rp.lbase);
-            for (uint32_t k = 0; k < cnt; ++k) {
-              const uint32_t j = (uint32_t)__ffsll((long long)mrem) - 1u;
-              mrem &= mrem - 1;
-              stage[loff + k] = s2[j].y;
-            }
-          } else {
-            const uint32_t nk = rp.kept ? (cnt < kPKeep ? cnt : kPKeep) : 0u;
-            for (uint32_t k = 0; k < nk; ++k) {
-              stage[loff + k] = kept[k];
-              mrem &= mrem - 1;
-            }
-            if (nk < cnt) {  // the rest is re-read next to its record
-              kargs_t p = fresh(ka);
-              const uint2 *rec = p->v.rec;
-              const uint32_t *idv = p->v.id;
-              for (uint32_t k = nk; k < cnt; k += kPGather) {
-                uint32_t ids[kPGather];
+      PSTAMP(tile, 1);
+    }
+
+    // ---- the next tile's ticket is out already (drawn an iteration ahead): its queries leave now -------------------
+    uint32_t ntile = 0xFFFFFFFFu;
+    Query nqy{0u, 0u, 0u, 0u, 0u};
+    if (live) {
+      TileSlot &nx = s_slot[(it + 1) % kRing];
+      lds_wait_eq(&nx.gen_ticket, it + 2);
+      ntile = __builtin_amdgcn_readfirstlane(nx.tile);
+      nqy = query_of(ntile);
+      PSTAMP(tile, 2);
+    }
+
+    // ---- the slice counted two iterations ago goes out (both pending ones when the batch is used up) -----------------
+    if (pb.have) flush(pb, it - 2);
+    if (!live) {
+      if (pa.have) flush(pa, it - 1);
+      break;
+    }
+    PSTAMP(tile, 3);
+
+    // ---- lay the new slice's ids out in the stage, back to back as they will sit in the output -------------------
+    pb = pa;
+    pa = Pending{true, staged, tile, wtotal, (loff << 16) | cnt};
+    uint32_t *const stage = s_stage[wave][it & 1u];
+    if (!staged) {
+      stage[3 * lane] = (uint32_t)lpos64;
+      stage[3 * lane + 1] = (uint32_t)(lpos64 >> 32);
+      stage[3 * lane + 2] = cnt;
+    } else if (!no_ids && cnt) {
+      uint64_t mrem = rp.mask;
+      if (rp.lds) {  // everything is in the wavefront's slab
+        const uint2 *s2 = reinterpret_cast<const uint2 *>(slab) + (rp.al - rp.lbase);
+        for (uint32_t k = 0; k < cnt; ++k) {
+          const uint32_t j = (uint32_t)__ffsll((long long)mrem) - 1u;
+          mrem &= mrem - 1;
+          stage[loff + k] = s2[j].y;
+        }
+      } else {
+        const uint32_t nk = rp.kept ? (cnt < kPKeep ? cnt : kPKeep) : 0u;
+        for (uint32_t k = 0; k < nk; ++k) {
+          stage[loff + k] = kept[k];
+          mrem &= mrem - 1;
+        }
+        if (nk < cnt) {  // the rest is re-read next to its record
+          kargs_t p = fresh(ka);
+          const uint2 *rec = p->v.rec;
+          const uint32_t *idv = p->v.id;
+          for (uint32_t k = nk; k < cnt; k += kPGather) {
+            uint32_t ids[kPGather];
 #pragma unroll
-                for (uint32_t i = 0; i < kPGather; ++i)
-                  if (k + i < cnt) {
-                    const uint32_t j = (uint32_t)__ffsll((long long)mrem) - 1u;
-                    mrem &= mrem - 1;
-                    ids[i] = rp.packed ? rec[rp.al + j].y : idv[rp.al + j];
-                  }
-#pragma unroll
-                for (uint32_t i = 0; i < kPGather; ++i)
-                  if (k + i < cnt) stage[loff + k + i] = ids[i];
+            for (uint32_t i = 0; i < kPGather; ++i)
+              if (k + i < cnt) {
+                const uint32_t j = (uint32_t)__ffsll((long long)mrem) - 1u;
+                mrem &= mrem - 1;
+                ids[i] = rp.packed ? rec[rp.al + j].y : idv[rp.al + j];
               }
-            }
+#pragma unroll
+            for (uint32_t i = 0; i < kPGather; ++i)
+              if (k + i < cnt) stage[loff + k + i] = ids[i];
           }
         }
-        wave_sync_lds();
       }
     }
-    PSTAMP(tile, 6);
+    wave_sync_lds();
+    PSTAMP(tile, 4);
     tile = ntile;
     qy = nqy;
-  }
-
-  // self-cleaning workspace: every workgroup bumps `done` when it leaves — its tiles are written, its sweeps long
-  // over, its last ticket drawn; the one that sees gridDim.x - 1 knows nobody touches the words any more and zeroes
-  // them for the next launch (the list of tiles for k_fill_tiles stays: that kernel clears its count).
-  if ((A(flags) & kFlagSelfClean) && wave == 0) {
-    uint64_t *ws = A(ws);
-    uint32_t last = 0;
-    if (lane == 0) last = atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1 ? 1u : 0u;
-    if (__shfl(last, 0, kWave)) {
-      const uint32_t ntiles = A(ntiles);
-      uint64_t *group = ws + kWsStatus, *status = group + kFMaxGroups;
-      for (uint32_t t = (uint32_t)lane; t < ntiles; t += kWave) {
-        status[t] = 0;
-        if (t < (ntiles + kWave - 1) / kWave) group[t] = 0;
-      }
-      if (lane == 0) {
-        ws[kWsTicket] = 0;
-        ws[kWsDone] = 0;
-      }
-    }
   }
 #undef A
 }
 
-// Fills the ids of the tiles k_query_pipe listed: offsets are in place, the enumeration is the general one
-// (k_query<Fill>'s, wavefront-cooperative windows included). One work item = a quarter tile (256 queries); the grid is
-// fixed and strides over the items, so the launch needs no host knowledge of the list; the last workgroup to finish
-// clears the count.
-__global__ __launch_bounds__(kQThreads) void k_fill_tiles(IndexView v, PipeArgs a) {
+// Fills the ids of the slices k_query_pipe listed: offsets are in place, the enumeration is the general one
+// (k_query<Fill>'s, wavefront-cooperative windows included). One work item = one slice (64 queries, one wavefront);
+// the grid is fixed and strides over the items, so the launch needs no host knowledge of the list; the last workgroup
+// to finish clears the count.
+__global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs a) {
   __shared__ SegDesc s_seg[kLdsSegs];
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ uint32_t s_last;
-  uint64_t *status = a.ws + kWsStatus + kFMaxGroups;
-  const uint32_t *todo = reinterpret_cast<const uint32_t *>(status + kFMaxTiles);
+  const uint32_t *todo = reinterpret_cast<const uint32_t *>(a.ws + kWsStatus + kFMaxGroups + kFMaxTiles);
   const uint32_t n =
       __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.ws + kWsTodo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (n == 0) return;  // (nothing was listed: nobody touched the counters either)
@@ -378,16 +496,17 @@ __global__ __launch_bounds__(kQThreads) void k_fill_tiles(IndexView v, PipeArgs 
   const uint2 *cs;
   stage_descriptors<true>(v, s_seg, s_cs, segs, cs);
   __syncthreads();
-  constexpr uint32_t kParts = kPThreads / kQThreads;
-  for (uint32_t w = blockIdx.x; w < n * kParts; w += gridDim.x) {
-    const uint32_t tile = todo[w / kParts];
-    const size_t q = a.q_begin + (size_t)tile * kPThreads + (size_t)(w % kParts) * kQThreads + threadIdx.x;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  for (uint32_t w = blockIdx.x * kQWaves + wave; w < n; w += gridDim.x * kQWaves) {
+    const uint32_t e = todo[w];
+    const size_t q = a.q_begin + (size_t)(e >> 4) * kPTile + (size_t)(e & 15u) * kWave + lane;
     const bool valid = q < a.q_end;
     const Query qy = load_query<false>(v, cs, a.qchrom, a.qlow, a.qhigh, q, valid);
     const uint64_t pos = valid ? a.offsets[q] : 0;
     (void)enumerate_hits<Mode::Fill, false>(v, segs, qy, a.hits, pos, a.cap, nullptr);
   }
   // every workgroup that saw a non-empty list reports; the last one clears the list for the next call
+  __syncthreads();
   if (threadIdx.x == 0)
     s_last = atomicAdd(reinterpret_cast<unsigned int *>(a.ws + kWsTodoDone), 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
@@ -401,21 +520,23 @@ __global__ __launch_bounds__(kQThreads) void k_fill_tiles(IndexView v, PipeArgs 
 
 // true if the pipelined kernel handled the launch (the caller falls back to k_query_fused otherwise)
 bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bool unordered) {
-  static const int mode = [] {  // BIVX_PIPE: 0 = never, 1 = when eligible (default), 2 = also for small batches (tests)
-    const char *e = std::getenv("BIVX_PIPE");
-    return e ? std::atoi(e) : 1;
-  }();
+  // BIVX_PIPE: 0 = never, 1 = when eligible (default), 2 = also for small batches (tests)
+  const char *env = std::getenv("BIVX_PIPE");
+  const int mode = env ? std::atoi(env) : 1;
   if (!mode || unordered || sort_ids || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
   // batches of a few tiles per resident workgroup gain nothing from a pipeline that has to fill and drain
   // (config 2, 977 tiles: 60 us against 55 for k_query_fused)
-  if (q < (size_t)4 * 512 * kPThreads && mode != 2) return false;
+  if (q < (size_t)4 * 512 * kPTile && mode != 2) return false;
   // few ids per query: a wavefront's 64 lists must fit its stage (the capacity is the only bound the host has)
   return cap <= (uint64_t)6 * q;
 }
 
+size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }
+
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
-                      size_t q0, size_t q1, unsigned tiles, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap,
-                      uint64_t *ws, int flags, hipStream_t s) {
+                      size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
+                      int flags, hipStream_t s) {
+  const unsigned tiles = (unsigned)((q1 - q0 + kPTile - 1) / kPTile);
   unsigned wgs = 512;
   {
     int dev = 0, cus = 0;
@@ -429,7 +550,7 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
   }
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags};
   hipLaunchKernelGGL(k_query_pipe, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
-  hipLaunchKernelGGL(k_fill_tiles, dim3(256), dim3(kQThreads), 0, s, v, a);
+  hipLaunchKernelGGL(k_fill_slices, dim3(256), dim3(kQThreads), 0, s, v, a);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

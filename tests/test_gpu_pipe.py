@@ -1,0 +1,163 @@
+"""The pipelined single-pass kernel (binary_amd/csrc/query_pipe.hip: persistent workgroups, worker and service
+wavefronts, output deferred by two iterations) against k_query_fused and the oracle. By default it only takes batches of
+2 M queries and more; BIVX_PIPE=2 sends every eligible batch through it, BIVX_PIPE=0 none, so the two kernels can be
+compared bit for bit on the same inputs: offsets AND ids in index order must be identical."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _both(idx, qlo, qhi, qc=None, cap=None, workspace=False):
+    """(offsets, hits) from the pipelined kernel and from k_query_fused, same buffers sizes"""
+    import torch
+    dev = qlo.device
+    q = qlo.numel()
+    off0 = idx.count_overlaps_device(qlo, qhi, qc)
+    H = int(off0[-1].item())
+    out = []
+    for mode in (2, 0):
+        with _env(BIVX_PIPE=mode):
+            off = torch.full((q + 1,), -1, dtype=torch.int64, device=dev)
+            hits = torch.full((max(H if cap is None else cap, 1),), -1, dtype=torch.int32, device=dev)
+            ws = torch.empty(idx.query_workspace_bytes(q), dtype=torch.uint8, device=dev) if workspace else None
+            idx.query_device(qlo, qhi, off, hits, workspace=ws, qchrom=qc)
+            idx.stream_status()
+            out.append((off.cpu().numpy(), hits.cpu().numpy()))
+    return H, out
+
+
+@pytest.mark.parametrize("order", ["generated", "sorted", "nearly"])
+@pytest.mark.parametrize("workspace", [False, True])
+def test_same_csr_as_the_fused_kernel_and_the_oracle(oracle, order, workspace):
+    import torch
+    from binary_amd import IntervalIndex, synth
+    d = synth.gen_genome(400_000, 300_007, 1000)       # 24 chromosomes; 313 tiles of 960 queries, a ragged last one
+    qc, qlo, qhi = d["qchrom"], d["qlow"], d["qhigh"]
+    if order != "generated":
+        p = np.lexsort((qlo, qc))
+        if order == "nearly":                            # sorted with every 50th query displaced
+            rng = np.random.default_rng(0)
+            sw = rng.permutation(p.size)[: p.size // 50]
+            p[sw] = p[np.roll(sw, 1)]
+        qc, qlo, qhi = qc[p], qlo[p], qhi[p]
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(d["low"], d["high"], d["chrom"])
+        idx.build()
+        H, ((off_p, hits_p), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi), to(qc), workspace=workspace)
+        assert np.array_equal(off_p, off_f) and np.array_equal(hits_p[:H], hits_f[:H])
+    # the oracle on a few chromosomes
+    for c in (0, 7, 23):
+        m = d["chrom"] == c
+        base = int(np.nonzero(m)[0][0])
+        t = oracle.OracleTree(d["low"][m], d["high"][m])
+        qm = np.nonzero(qc == c)[0][:4000]
+        off_o, hits_o = t.find_overlaps_batch(qlo[qm], qhi[qm])
+        got = np.concatenate([np.sort(hits_p[off_p[i]:off_p[i + 1]]) for i in qm]).astype(np.int64)
+        assert np.array_equal(got, oracle.sorted_csr(off_o, hits_o) + base)
+
+
+def test_slices_that_cannot_be_staged_are_filled_behind_the_kernel(oracle):
+    """Wavefront-cooperative windows (a few chromosome-wide queries among point queries) and lists beyond a stage: the
+    slice is listed, k_fill_slices writes its ids; everything else goes through the stages."""
+    import torch
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(3)
+    n = 150_000
+    low = rng.integers(0, 3_000_000, n).astype(np.uint32)
+    high = (low + rng.integers(1, 400, n)).astype(np.uint32)
+    q = 60_000
+    qlo = rng.integers(0, 3_000_000, q).astype(np.uint32)
+    qhi = qlo.copy()
+    wide = rng.permutation(q)[:40]
+    qlo[wide] = rng.integers(0, 1_000_000, 40)
+    qhi[wide] = qlo[wide] + rng.integers(20_000, 200_000, 40)   # hundreds to thousands of hits each
+    dense = np.arange(5000, 5400)                                # neighbouring queries with ~40 hits each: lists overflow a stage
+    qlo[dense] = 1_500_000 + np.arange(400)
+    qhi[dense] = qlo[dense] + 800
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        H, ((off_p, hits_p), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi))
+        assert np.array_equal(off_p, off_f) and np.array_equal(hits_p[:H], hits_f[:H])
+        # a buffer that is too small: offsets stay exact, nothing is written beyond the capacity
+        cap = H // 3
+        H2, ((off_c, hits_c), _) = _both(idx, to(qlo), to(qhi), cap=cap)
+        assert np.array_equal(off_c, off_f) and np.array_equal(hits_c[:cap], hits_f[:cap])
+    assert np.array_equal(np.diff(off_p), oracle.count_overlaps_numpy(low, high, qlo, qhi))
+
+
+def test_chained_launches_and_few_workgroups():
+    import torch
+    from binary_amd import IntervalIndex, synth
+    low, high = synth.gen_intervals(200_000, 50_000_000, 1000)
+    qlo, qhi = synth.gen_range_queries(100_001, 50_000_000, 1000)
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        H, ((off_ref, hits_ref), _) = _both(idx, to(qlo), to(qhi))
+        for knobs in (dict(BIVX_MAX_TILES_PER_LAUNCH=7), dict(BIVX_PIPE_WGS=1), dict(BIVX_PIPE_WGS=3)):
+            with _env(**knobs):
+                H2, ((off_p, hits_p), _) = _both(idx, to(qlo), to(qhi))
+            assert np.array_equal(off_p, off_ref) and np.array_equal(hits_p[:H], hits_ref[:H]), knobs
+        # a pure count through the pipelined kernel
+        with _env(BIVX_PIPE=2):
+            off = idx.count_overlaps_device(to(qlo), to(qhi))
+            idx.stream_status()
+        assert np.array_equal(off.cpu().numpy(), off_ref)
+        assert idx.stats()["prefix_timeouts"] == 0
+
+
+def test_errors_are_surfaced_by_the_pipelined_kernel_too():
+    import ctypes as C
+    import torch
+    from binary_amd import IntervalIndex, capi, synth
+    low, high = synth.gen_intervals(100_000, 20_000_000, 1000)
+    qlo, qhi = synth.gen_range_queries(200_000, 20_000_000, 1000)
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    d_qlo, d_qhi = to(qlo), to(qhi)
+    with IntervalIndex(0) as idx, _env(BIVX_PIPE=2):
+        idx.insert_node(low, high)
+        idx.build()
+        off, hits = idx.find_overlaps_device(d_qlo, d_qhi)
+        idx.stream_status()
+        ref_off, ref_hits = off.clone(), hits.clone()
+        idx.query_device(d_qlo, d_qhi, off, hits)
+        idx.stream_status()
+        assert torch.equal(off, ref_off) and torch.equal(hits, ref_hits)
+        # an inconsistent workspace (the ticket word of a launch that died half-way)
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        capi.check(idx._L.bivx_debug_corrupt_workspace(idx._h, s))
+        idx.query_device(d_qlo, d_qhi, off, hits)
+        with pytest.raises(capi.BivxError) as e:
+            idx.stream_status()
+        assert e.value.code == capi.E_TIMEOUT
+        idx.query_device(d_qlo, d_qhi, off, hits)       # cleared before this launch
+        idx.stream_status()
+        assert torch.equal(off, ref_off) and torch.equal(hits, ref_hits)

@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 SORTED = "--sorted" in sys.argv
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "clean"])
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "-j8", "EXTRA=-DBIVX_STAMPS"])
+os.environ["BIVX_PIPE"] = "2"
 from binary_amd import IntervalIndex, synth, capi  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -38,13 +39,17 @@ buf = (C.c_ulonglong * n)()
 assert capi.load().bivx_debug_pstamps(buf, n) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
 st = st[st[:, 0] > 0]
-us = (st[:, :7] - st[:, 0].min()) / 100.0
-names = ["iteration start", "counted (wave 0)", "barrier A", "published + swept (wave 0)", "barrier B", "pending tile out",
-         "ids laid out"]
-dd = np.diff(us, axis=1)
+# stamps of worker wavefront 0, per tile: 0 counting starts, 1 total reported, 2 next ticket seen + its queries issued,
+# 3 (of the tile flushed one iteration later) pending slice out, 4 ids laid out
+us = (st[:, :5] - st[:, 0].min()) / 100.0
 print(f"tiles stamped: {len(st)}")
-for k in range(6):
-    print(f"  {names[k]:>28s} -> {names[k+1]:<28s} median {np.median(dd[:, k]):6.2f}  p90 {np.percentile(dd[:, k], 90):6.2f}")
-print(f"  whole iteration: median {np.median(us[:, 6] - us[:, 0]):6.2f}  p90 {np.percentile(us[:, 6] - us[:, 0], 90):6.2f}")
+for a, b, nm in ((0, 1, "counting"), (1, 2, "wait for the next ticket + issue its queries"),
+                 (2, 3, "the slice of two iterations ago goes out (incl. wait for its base)"), (3, 4, "lay the new slice's ids out")):
+    dd = us[:, b] - us[:, a]
+    dd = dd[(dd > 0) & (dd < 1000)]
+    print(f"  {nm:68s} median {np.median(dd):6.2f}  p90 {np.percentile(dd, 90):6.2f}")
+dd = us[:, 4] - us[:, 0]
+dd = dd[(dd > 0) & (dd < 1000)]
+print(f"  whole iteration (worker 0): median {np.median(dd):6.2f}  p90 {np.percentile(dd, 90):6.2f}")
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "clean"])
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "-j8"])
