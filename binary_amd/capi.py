@@ -19,7 +19,7 @@ EXPORTS = (
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
     "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f", "bivx_query_dev_s", "bivx_query_dev_u",
-    "bivx_find_overlaps", "bivx_free", "bivx_stream_status", "bivx_debug_corrupt_workspace",
+    "bivx_find_overlaps", "bivx_free", "bivx_stream_status", "bivx_query_kernel_name", "bivx_debug_corrupt_workspace",
 )
 
 
@@ -85,6 +85,8 @@ def load() -> C.CDLL:
     L.bivx_fill.argtypes = [vp, u32p, u32p, u32p, sz, u64p, u32p, C.c_int]
     L.bivx_count_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, vp]
     L.bivx_stream_status.argtypes = [vp, vp]
+    L.bivx_query_kernel_name.argtypes = [vp, sz, C.c_uint64, C.c_int, vp]
+    L.bivx_query_kernel_name.restype = C.c_char_p
     L.bivx_debug_corrupt_workspace.argtypes = [vp, vp]
     L.bivx_fill_dev.argtypes = [vp, u32p, u32p, u32p, sz, u64p, u32p, vp]
     L.bivx_query_workspace_bytes.argtypes = [sz]

@@ -125,6 +125,10 @@ class IntervalIndex:
     def num_chroms(self) -> int:
         return int(self._L.bivx_num_chroms(self._h))
 
+    def query_kernel_name(self, q: int, hit_capacity: int, sort_by_id: bool = False) -> str:
+        """Name of the kernel query_device runs for a batch of q queries into a buffer of hit_capacity ids."""
+        return self._L.bivx_query_kernel_name(self._h, int(q), int(hit_capacity), 1 if sort_by_id else 0, None).decode()
+
     def num_devices(self) -> int:
         return int(self._L.bivx_num_devices(self._h))
 

@@ -172,6 +172,13 @@ int bivx_query_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32
  * that every status is surfaced). */
 int bivx_stream_status(const bivx_index *idx, void *stream);
 
+/* Which kernel bivx_query_dev* runs for such a call: "k_query_pipe" (the pipelined form, for batches of about 2 M
+ * queries and more on an index with one length class per chromosome, no post-filter, index order, at most 6 ids per
+ * query of capacity) or "k_query_fused" (everything else). Same results either way; the name is what shows up in a
+ * rocprofv3 kernel trace (bench.py reports it as the dominant kernel). */
+const char *bivx_query_kernel_name(const bivx_index *idx, size_t q, uint64_t hit_capacity, int sort_by_id,
+                                   const bivx_filter *filter);
+
 /* sorts every query's hit list ascending by id, in place */
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q,
                        void *stream);

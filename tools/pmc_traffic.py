@@ -12,8 +12,12 @@ import sys
 from collections import defaultdict
 
 acc = defaultdict(list)
+KERNEL = "k_query_fused"
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "k_query_fused" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "k_query_fused" in r["Kernel_Name"] or "k_query_pipe" in r["Kernel_Name"]]
+    if any("k_query_pipe" in r["Kernel_Name"] for r in rows):  # the steps run the pipelined kernel (the sizing count too)
+        rows = [r for r in rows if "k_query_pipe" in r["Kernel_Name"]]
+        KERNEL = "k_query_pipe"
     # the first launch of the kernel in a bench run is the zero-capacity count that sizes the hit buffer, not a step
     first = min((int(r["Dispatch_Id"]) for r in rows), default=None)
     for r in rows:
@@ -28,7 +32,7 @@ wr = avg.get("TCC_EA0_WRREQ_sum", 0.0)
 wr64 = avg.get("TCC_EA0_WRREQ_64B_sum", 0.0)
 write_bytes_req = wr64 * 64 + (wr - wr64) * 32
 out = {
-    "kernel": "k_query_fused", "launches_sampled": len(acc.get("TCC_EA0_RDREQ_sum", [])),
+    "kernel": KERNEL, "launches_sampled": len(acc.get("TCC_EA0_RDREQ_sum", [])),
     "counters_avg_per_launch": avg,
     "read_bytes_per_launch": read_bytes,
     "fetch_size_bytes_per_launch_uncorrected": avg.get("FETCH_SIZE", 0.0) * 1024,
