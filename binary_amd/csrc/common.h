@@ -164,6 +164,6 @@ bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bo
 size_t pipe_queries_per_launch();
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
-                      int flags, hipStream_t s);
+                      int flags, uint32_t sort_seq, hipStream_t s);
 
 }  // namespace bivx

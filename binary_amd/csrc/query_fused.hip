@@ -487,14 +487,14 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
     // ordered by k_sort_hits afterwards, whose stage is eight times larger.
     const bool sort_inside = sort_ids && !unordered && cap <= (uint64_t)kFusedSortMaxAvg * q;
-    if (use_pipe) {
-      if (int rc = launch_query_pipe(v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, flags, s))
-        return rc;
-      continue;
-    }
     static std::atomic<uint32_t> launch_seq{1};
     uint32_t seq = launch_seq.fetch_add(1);
     if (seq == 0) seq = launch_seq.fetch_add(1);  // 0 is what a cleared workspace holds
+    if (use_pipe) {
+      if (int rc = launch_query_pipe(v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, flags,
+                                     sort_ids ? seq : 0u, s))
+        return rc;
+    } else {
 #define BIVX_LAUNCH_FUSED_V(L, FL, SO, MSV, UV)                                                               \
   hipLaunchKernelGGL((k_query_fused<L, FL, SO, MSV, UV>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, \
                      q1, d_offsets, d_hits, cap, ws, flags, d_counts, d_total, seq)
@@ -525,6 +525,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
 #endif
 #undef BIVX_LAUNCH_FUSED
 #undef BIVX_LAUNCH_FUSED_V
+    }
     if (sort_ids && !unordered) {
       BIVX_HIP(hipGetLastError());
       // ordered inside the kernel: the pass only runs if a wavefront asked for it (it compares the word with seq)

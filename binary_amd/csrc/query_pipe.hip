@@ -62,6 +62,7 @@ struct PipeArgs {
   uint64_t *ws;
   uint32_t ntiles;
   int flags;
+  uint32_t seq;   // != 0: ids ascending inside every query; the word k_fill_slices leaves for the conditional k_sort_hits
 };
 
 // The kernel's arguments stay where the launch put them — the kernarg segment, constant memory — and are re-read
@@ -105,6 +106,8 @@ __device__ __forceinline__ void lds_wait_eq(const uint32_t *p, uint32_t x) {
   while (lds_load(p) != x) __builtin_amdgcn_s_sleep(1);
 }
 
+// S: every query's ids leave in ascending order (ordered by their lane while they sit in the stage).
+template <bool S>
 __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, PipeArgs a_in) {
   (void)v_in;
   (void)a_in;
@@ -472,6 +475,31 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         }
       }
     }
+    if (S && staged && !no_ids) {
+      // Every lane orders its own list where it lies (ids are distinct inside a query): up to eight ids are ranked in
+      // registers; a longer list is ranked into the keep slots, which are idle until the next tile is counted, and
+      // copied back. Lane-local throughout — a wavefront's LDS operations execute in order, nothing to wait for.
+      wave_sync_lds();  // (the slab next door may still be read by this wavefront's other lanes)
+      if (cnt > 1 && cnt <= 8u) {
+        uint32_t x[8], rank[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) x[k] = k < cnt ? stage[loff + k] : 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+          rank[k] = 0;
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; ++j)
+            if (j != k) rank[k] += x[j] < x[k] ? 1u : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+          if (k < cnt) stage[loff + rank[k]] = x[k];
+      } else if (cnt > 8u) {
+        uint32_t *const tmp = reinterpret_cast<uint32_t *>(slab);
+        rank_sort_list<8>(stage, tmp, loff, cnt);
+        for (uint32_t k = 0; k < cnt; ++k) stage[loff + k] = tmp[loff + k];
+      }
+    }
     wave_sync_lds();
     PSTAMP(tile, 4);
     tile = ntile;
@@ -505,6 +533,9 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
     const uint64_t pos = valid ? a.offsets[q] : 0;
     (void)enumerate_hits<Mode::Fill, false>(v, segs, qy, a.hits, pos, a.cap, nullptr);
   }
+  // these lists are in index order: the conditional k_sort_hits behind this kernel orders them if ascending ids were asked for
+  if (a.seq != 0 && threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(a.ws + kWsNeedSort), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // every workgroup that saw a non-empty list reports; the last one clears the list for the next call
   __syncthreads();
   if (threadIdx.x == 0)
@@ -523,7 +554,7 @@ bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bo
   // BIVX_PIPE: 0 = never, 1 = when eligible (default), 2 = also for small batches (tests)
   const char *env = std::getenv("BIVX_PIPE");
   const int mode = env ? std::atoi(env) : 1;
-  if (!mode || unordered || sort_ids || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
+  if (!mode || unordered || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
   // batches of a few tiles per resident workgroup gain nothing from a pipeline that has to fill and drain
   // (config 2, 977 tiles: 60 us against 55 for k_query_fused)
   if (q < (size_t)4 * 512 * kPTile && mode != 2) return false;
@@ -535,7 +566,7 @@ size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }
 
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
-                      int flags, hipStream_t s) {
+                      int flags, uint32_t sort_seq, hipStream_t s) {
   const unsigned tiles = (unsigned)((q1 - q0 + kPTile - 1) / kPTile);
   unsigned wgs = 512;
   {
@@ -548,8 +579,11 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
     }
   }
-  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags};
-  hipLaunchKernelGGL(k_query_pipe, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
+  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, sort_seq};
+  if (sort_seq)
+    hipLaunchKernelGGL(k_query_pipe<true>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
+  else
+    hipLaunchKernelGGL(k_query_pipe<false>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   hipLaunchKernelGGL(k_fill_slices, dim3(256), dim3(kQThreads), 0, s, v, a);
   BIVX_HIP(hipGetLastError());
   return 0;

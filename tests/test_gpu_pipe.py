@@ -27,7 +27,7 @@ class _env:
                 os.environ[k] = v
 
 
-def _both(idx, qlo, qhi, qc=None, cap=None, workspace=False):
+def _both(idx, qlo, qhi, qc=None, cap=None, workspace=False, sort_by_id=False):
     """(offsets, hits) from the pipelined kernel and from k_query_fused, same buffers sizes"""
     import torch
     dev = qlo.device
@@ -40,15 +40,15 @@ def _both(idx, qlo, qhi, qc=None, cap=None, workspace=False):
             off = torch.full((q + 1,), -1, dtype=torch.int64, device=dev)
             hits = torch.full((max(H if cap is None else cap, 1),), -1, dtype=torch.int32, device=dev)
             ws = torch.empty(idx.query_workspace_bytes(q), dtype=torch.uint8, device=dev) if workspace else None
-            idx.query_device(qlo, qhi, off, hits, workspace=ws, qchrom=qc)
+            idx.query_device(qlo, qhi, off, hits, workspace=ws, qchrom=qc, sort_by_id=sort_by_id)
             idx.stream_status()
             out.append((off.cpu().numpy(), hits.cpu().numpy()))
     return H, out
 
 
 @pytest.mark.parametrize("order", ["generated", "sorted", "nearly"])
-@pytest.mark.parametrize("workspace", [False, True])
-def test_same_csr_as_the_fused_kernel_and_the_oracle(oracle, order, workspace):
+@pytest.mark.parametrize("workspace,by_id", [(False, False), (True, False), (False, True)])
+def test_same_csr_as_the_fused_kernel_and_the_oracle(oracle, order, workspace, by_id):
     import torch
     from binary_amd import IntervalIndex, synth
     d = synth.gen_genome(400_000, 300_007, 1000)       # 24 chromosomes; 313 tiles of 960 queries, a ragged last one
@@ -65,8 +65,12 @@ def test_same_csr_as_the_fused_kernel_and_the_oracle(oracle, order, workspace):
     with IntervalIndex(0) as idx:
         idx.insert_node(d["low"], d["high"], d["chrom"])
         idx.build()
-        H, ((off_p, hits_p), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi), to(qc), workspace=workspace)
+        H, ((off_p, hits_p), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi), to(qc), workspace=workspace,
+                                                       sort_by_id=by_id)
         assert np.array_equal(off_p, off_f) and np.array_equal(hits_p[:H], hits_f[:H])
+        if by_id:   # ascending inside every query: no descent anywhere except at a query's first id
+            desc = np.nonzero(np.diff(hits_p[:H].astype(np.int64)) < 0)[0] + 1
+            assert np.isin(desc, off_p).all()
     # the oracle on a few chromosomes
     for c in (0, 7, 23):
         m = d["chrom"] == c
@@ -103,11 +107,51 @@ def test_slices_that_cannot_be_staged_are_filled_behind_the_kernel(oracle):
         idx.build()
         H, ((off_p, hits_p), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi))
         assert np.array_equal(off_p, off_f) and np.array_equal(hits_p[:H], hits_f[:H])
+        # ascending ids: the staged lists are ordered in the stage (lists of 40 ids go through the keep slots), the
+        # listed slices by the conditional pass behind k_fill_slices
+        H1, ((off_s, hits_s), (off_fs, hits_fs)) = _both(idx, to(qlo), to(qhi), sort_by_id=True)
+        assert np.array_equal(off_s, off_f) and np.array_equal(hits_s[:H], hits_fs[:H])
+        want = np.concatenate([np.sort(hits_f[off_f[i]:off_f[i + 1]]) for i in range(q)])
+        assert np.array_equal(hits_s[:H], want)
         # a buffer that is too small: offsets stay exact, nothing is written beyond the capacity
         cap = H // 3
         H2, ((off_c, hits_c), _) = _both(idx, to(qlo), to(qhi), cap=cap)
         assert np.array_equal(off_c, off_f) and np.array_equal(hits_c[:cap], hits_f[:cap])
     assert np.array_equal(np.diff(off_p), oracle.count_overlaps_numpy(low, high, qlo, qhi))
+
+
+def test_ascending_ids_for_lists_of_every_staged_length():
+    """Lists of 0..60 ids next to each other in a wavefront's stage: up to eight ids are ranked in registers, longer
+    ones through the keep slots; the slices whose 64 lists exceed a stage are listed and ordered behind the kernel."""
+    import torch
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(11)
+    # piles of k intervals over the same point, k = 0..60, 5000 positions apart; ids shuffled so index order != id order
+    pos = np.arange(1, 4001, dtype=np.uint32) * 5000
+    k = rng.integers(0, 61, pos.size)
+    few = rng.random(pos.size) < 0.8
+    k[few] = rng.integers(0, 5, int(few.sum()))
+    centre = np.repeat(pos, k)
+    low = (centre - rng.integers(1, 2000, centre.size)).astype(np.uint32)
+    high = (centre + rng.integers(1, 2000, centre.size)).astype(np.uint32)
+    p = rng.permutation(low.size)
+    low, high = low[p], high[p]
+    q = 120_000
+    qlo = pos[rng.integers(0, pos.size, q)].astype(np.uint32)
+    qhi = qlo.copy()
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        H, ((off_s, hits_s), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi), sort_by_id=True)
+        H0, ((off_u, hits_u), _) = _both(idx, to(qlo), to(qhi))
+    assert np.array_equal(off_s, off_f) and np.array_equal(hits_s[:H], hits_f[:H]) and np.array_equal(off_u, off_s)
+    cnt = np.diff(off_s)
+    assert cnt.max() >= 40 and (cnt == 0).any() and ((cnt > 8) & (cnt < 30)).any()
+    seg = np.repeat(np.arange(q), cnt)
+    order = np.lexsort((hits_u[:H], seg))
+    assert np.array_equal(hits_s[:H], hits_u[:H][order])
 
 
 def test_chained_launches_and_few_workgroups():
