@@ -62,20 +62,48 @@ __device__ __forceinline__ Window seg_window(const IndexView &v, const SegDesc &
   return w;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, kWave);
+// Wavefront reductions and the 64-lane prefix sum on the DPP datapath (gfx9 row_shr / row_bcast): six VALU instructions
+// each and no LDS round trip (the __shfl forms are a ds_bpermute plus its address arithmetic per step — 6 LDS round
+// trips and ~24 VALU instructions for one scan). All 64 lanes must be active. A lane without a source (row_shr across
+// the start of a row, rows masked out of a row_bcast step) combines with `old`, the identity of the operation — which is
+// also what lets the compiler fold the move into the arithmetic instruction (v_add_u32_dpp, v_max_u32_dpp).
+template <int CTRL, int ROWS = 0xF>
+__device__ __forceinline__ uint32_t dpp_from(uint32_t old, uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, ROWS, 0xF, false);
+}
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;  // lane 15 of a row to the next row; lane 31 to rows 2 and 3
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+  x += dpp_from<kDppShr1>(0u, x);
+  x += dpp_from<kDppShr2>(0u, x);
+  x += dpp_from<kDppShr4>(0u, x);
+  x += dpp_from<kDppShr8>(0u, x);
+  x += dpp_from<kDppBcast15, 0xA>(0u, x);
+  x += dpp_from<kDppBcast31, 0xC>(0u, x);
   return x;
 }
+__device__ __forceinline__ uint32_t wave_last(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, kWave - 1); }
+// (the results below are wavefront-uniform: lane 63 of the running form holds the reduction)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return wave_last(wave_scan_incl(x)); }
 __device__ __forceinline__ uint32_t wave_max(uint32_t x) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) x = max(x, (uint32_t)__shfl_xor(x, d, kWave));
-  return x;
+  x = max(x, dpp_from<kDppShr1>(0u, x));
+  x = max(x, dpp_from<kDppShr2>(0u, x));
+  x = max(x, dpp_from<kDppShr4>(0u, x));
+  x = max(x, dpp_from<kDppShr8>(0u, x));
+  x = max(x, dpp_from<kDppBcast15, 0xA>(0u, x));
+  x = max(x, dpp_from<kDppBcast31, 0xC>(0u, x));
+  return wave_last(x);
 }
 __device__ __forceinline__ uint32_t wave_min(uint32_t x) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) x = min(x, (uint32_t)__shfl_xor(x, d, kWave));
-  return x;
+  x = min(x, dpp_from<kDppShr1>(~0u, x));
+  x = min(x, dpp_from<kDppShr2>(~0u, x));
+  x = min(x, dpp_from<kDppShr4>(~0u, x));
+  x = min(x, dpp_from<kDppShr8>(~0u, x));
+  x = min(x, dpp_from<kDppBcast15, 0xA>(~0u, x));
+  x = min(x, dpp_from<kDppBcast31, 0xC>(~0u, x));
+  return wave_last(x);
 }
 
 // ---- fused post-filters (include/bivx.h, bivx_filter) -----------------------------------------------------------
@@ -231,6 +259,51 @@ __device__ __forceinline__ uint64_t light_mask_packed_lds(const IndexView &v, co
   return mask;
 }
 
+// The common case of the slab, without a branch: every window of the wavefront is shorter than 32 slots, so the hit mask
+// is one word. All lanes walk the same number of 8-slot chunks (the longest window's); a chunk is four 16-byte LDS
+// reads whatever the window's end — what lies beyond is evaluated like the rest and masked off at the end with the
+// window's own bits. Coordinates are taken relative to the window's first cell, where a record's low is its 16 stored
+// bits minus the cell's (mod 65536): hit <=> low <= q.high and low + length >= q.low. The mask is built by doubling
+// (m = 2m + hit, one add-with-carry per record) and reversed once.
+// m = 2m + (a1 <= b1 && a2 >= b2) in three vector instructions: the two comparisons' lane masks (llvm.amdgcn.icmp,
+// predicates 37 = ule, 35 = uge) are and-ed on the scalar unit and become the carry-in of an add-with-carry
+__device__ __forceinline__ uint32_t shift_in_le_ge(uint32_t m, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+  uint32_t r;
+  const uint64_t cc = __builtin_amdgcn_uicmp(a1, b1, 37) & __builtin_amdgcn_uicmp(a2, b2, 35);
+  asm("v_addc_co_u32 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(m), "s"(cc) : "vcc");
+  return r;
+}
+
+__device__ __forceinline__ uint32_t slab_mask32(const uint4 *slab, uint32_t lbase, const Window &w, uint32_t lo,
+                                                uint32_t hi, bool nonempty) {
+  const uint32_t al = w.a & ~1u;
+  const uint32_t nch = wave_max(nonempty ? (w.b - al + 7u) >> 3 : 0u);
+  if (nch == 0) return 0u;
+  const uint4 *sp = slab + (nonempty ? (al - lbase) >> 1 : 0u);
+  const uint32_t base = w.cell0_low;
+  const uint32_t qh = hi - base, ql = lo > base ? lo - base : 0u;
+  uint32_t m = 0;
+#pragma unroll 1
+  for (uint32_t c = 0; c < nch; ++c) {
+    uint4 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = sp[4 * c + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t rr[2] = {r[j].x, r[j].z};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint32_t rl = (rr[e] - base) & 0xFFFFu;
+        const uint32_t rh = rl + (rr[e] >> 16);
+        m = shift_in_le_ge(m, rl, qh, rh, ql);
+      }
+    }
+  }
+  m = __brev(m) >> (32u - 8u * nch);
+  const uint32_t wm = nonempty ? ((1u << (w.b - w.a)) - 1u) << (w.a - al) : 0u;
+  return m & wm;
+}
+
 // First slot in [a, b) whose low is >= x (b if there is none), found by the whole wavefront: a 64-ary search — the
 // 64 lanes probe 64 evenly spaced slots, one __ballot tells which gap holds the answer, repeat. Used to trim long
 // candidate windows (many intervals starting inside one directory cell) to the slots whose low lies in
@@ -353,6 +426,19 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
         wave_sync_lds();
       }
       in_slab = in_slab && slab_on;
+      if (!MS && !F && slab_on && rp) {
+        const bool shortw = in_slab && w.b - (w.a & ~1u) < 32u;
+        if (!__any(nonempty && !shortw)) {
+          const uint32_t m = slab_mask32(slab, lbase, w, lo, hi, nonempty);
+          rp->al = w.a & ~1u;
+          rp->mask = m;
+          rp->packed = true;
+          rp->lds = true;
+          rp->lbase = lbase;
+          rp->nrec = 1;
+          return (uint32_t)__popc(m);
+        }
+      }
     }
     if (nonempty && !heavy) {
       uint32_t al;

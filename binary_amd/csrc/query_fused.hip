@@ -136,12 +136,7 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
 
   BIVX_STAMP(2);
   // workgroup exclusive scan of the per-thread sums
-  uint32_t incl = tsum;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const uint32_t o = __shfl_up(incl, d, kWave);
-    if (lane >= d) incl += o;
-  }
+  const uint32_t incl = wave_scan_incl(tsum);
   if (lane == kWave - 1) s_wsum[wave] = incl;
   // 32-bit sums are exact while every query of the tile has fewer than 2^22 hits (1024 * 2^22 = 2^32). A tile
   // with a larger list (chromosome-wide queries on a very large index) redoes the scan in 64 bits.

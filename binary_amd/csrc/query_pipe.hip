@@ -380,16 +380,11 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, true>(v1, segs, qy, nullptr, 0, 0, &rp, kept,
                                                                            nullptr, slab);
       }
-      uint32_t incl = cnt;
-#pragma unroll
-      for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, kWave);
-        if (lane >= d) incl += o;
-      }
+      const uint32_t incl = wave_scan_incl(cnt);
       loff = incl - cnt;
       // (2^22 hits in one lane would overflow the 32-bit scan: such a slice is never staged and is counted in 64 bits)
       const bool huge = __any(cnt >= (1u << 22));
-      wtotal = __builtin_amdgcn_readfirstlane(__shfl(incl, kWave - 1, kWave));
+      wtotal = wave_last(incl);
       no_ids = A(cap) == 0;
       staged = !huge && (no_ids ? wtotal < 65536u : !__any(!rp.ok) && wtotal <= kPStage);
       uint64_t wt64 = wtotal;
@@ -442,7 +437,16 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       stage[3 * lane + 2] = cnt;
     } else if (!no_ids && cnt) {
       uint64_t mrem = rp.mask;
-      if (rp.lds) {  // everything is in the wavefront's slab
+      if (rp.lds && !__any((uint32_t)(rp.mask >> 32) != 0u)) {  // ... and every window is shorter than 32 slots
+        const uint2 *s2 = reinterpret_cast<const uint2 *>(slab) + (rp.al - rp.lbase);
+        uint32_t m32 = (uint32_t)rp.mask;
+        uint32_t *dst = stage + loff;
+        while (m32) {
+          const uint32_t j = (uint32_t)__ffs((int)m32) - 1u;
+          m32 &= m32 - 1u;
+          *dst++ = s2[j].y;
+        }
+      } else if (rp.lds) {  // everything is in the wavefront's slab
         const uint2 *s2 = reinterpret_cast<const uint2 *>(slab) + (rp.al - rp.lbase);
         for (uint32_t k = 0; k < cnt; ++k) {
           const uint32_t j = (uint32_t)__ffsll((long long)mrem) - 1u;
