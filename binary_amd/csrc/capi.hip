@@ -385,6 +385,7 @@ IndexView view_of(const bivx_index *idx, uint32_t svtype = 0) {
   v.nchrom = idx->nchrom;
   v.nseg = idx->nseg;
   v.max_segs = row < idx->max_segs.size() ? idx->max_segs[row] : 0;
+  v.nslots = idx->built_n < 0xFFFFFFFFull ? (uint32_t)idx->built_n : 0xFFFFFFFFu;
   v.flt_kind = BIVX_FILTER_NONE;
   v.flt_dist = 0;
   v.flt_strand = 0;

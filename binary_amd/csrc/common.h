@@ -58,6 +58,7 @@ struct IndexView {
   uint32_t nchrom;
   uint32_t nseg;
   uint32_t max_segs;          // most segments any one chromosome has (for the selected type)
+  uint32_t nslots;            // sorted slots (= intervals built) — saturates at 2^32 - 1
   // optional post-filter fused into the enumeration (bivx_filter): a candidate must pass it as well
   uint32_t flt_kind;          // BIVX_FILTER_*
   uint32_t flt_dist;

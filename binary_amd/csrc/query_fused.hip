@@ -521,7 +521,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
 #undef BIVX_LAUNCH_FUSED
 #undef BIVX_LAUNCH_FUSED_V
     }
-    if (sort_ids && !unordered) {
+    if (sort_ids && !unordered && !use_pipe) {  // (the pipelined kernel and k_fill_slices order every list themselves)
       BIVX_HIP(hipGetLastError());
       // ordered inside the kernel: the pass only runs if a wavefront asked for it (it compares the word with seq)
       if (int rc = launch_sort_hits(d_offsets + q0, d_hits, q1 - q0, cap, s,

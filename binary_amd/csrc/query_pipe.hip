@@ -41,7 +41,6 @@ constexpr uint32_t kPTile = kWorkers * kWave;  // 960 queries
 constexpr uint32_t kRing = 8;                  // tile slots in LDS
 constexpr uint32_t kPStage = 320;   // ids per wavefront stage (there are two: a slice waits two iterations for its base)
 constexpr uint32_t kPKeep = 8;      // ids kept per query while counting (a wavefront's 64 x 8 slots are its slab too)
-constexpr uint32_t kPGather = 4;    // ids a lane re-reads per step when more than kPKeep were found outside the slab
 
 // Diagnostic build only (-DBIVX_STAMPS): wall-clock stamps of worker 0, written to a buffer no other code reads.
 #ifdef BIVX_STAMPS
@@ -62,7 +61,7 @@ struct PipeArgs {
   uint64_t *ws;
   uint32_t ntiles;
   int flags;
-  uint32_t seq;   // != 0: ids ascending inside every query; the word k_fill_slices leaves for the conditional k_sort_hits
+  uint32_t seq;   // != 0: ids ascending inside every query
 };
 
 // The kernel's arguments stay where the launch put them — the kernarg segment, constant memory — and are re-read
@@ -104,6 +103,74 @@ __device__ __forceinline__ void lds_store(uint32_t *p, uint32_t x) {
 // (uniform per wavefront: every lane polls the same word)
 __device__ __forceinline__ void lds_wait_eq(const uint32_t *p, uint32_t x) {
   while (lds_load(p) != x) __builtin_amdgcn_s_sleep(1);
+}
+
+// A query's candidate window, worked out ahead of the counting (bucket directory probe): slots [a, b), the coordinate of
+// its first cell, and what kind it is.
+struct Win {
+  uint32_t a, b, base;
+  uint32_t fl;  // 1: not empty; 2: packed records decodable (a packed segment's window over at most 65536 coordinates)
+};
+
+// Hit mask of a window shorter than 32 slots, read by its own lane (queries in arbitrary order: the windows of a
+// wavefront are scattered over the index). The first sixteen slots — two chunks, up to eight 16-byte loads — leave
+// together, so a window that straddles two chunks costs one round trip, not two; a load is issued only by the lanes whose
+// window reaches its pair (the texture-address unit's time goes by lane, 1.3 lane-loads per cycle and CU measured:
+// tools/ub_gather.hip — clamped duplicates are not free). Evaluation as in slab_mask32, in ascending slot order; the
+// ids of the first KEEP hits go to the lane's keep slots as they are found. Windows of 17..31 slots (a
+// wavefront-uniform branch, rare) take a second round.
+// `wm16`: the window's own bits among the sixteen slots starting at the even slot 2 * p0 — what a predicated-off load
+// left in its registers is evaluated like the rest and masked off. The ids of the hits then go to the lane's keep
+// slots in slot order without a branch: every slot's id is stored at the running position, which advances only past a
+// hit (so a later store overwrites what a non-hit left), and stops at the last keep slot — which therefore holds
+// garbage once KEEP or more hits were found: the caller takes KEEP - 1 ids from the slots in that case.
+template <uint32_t KEEP>
+__device__ __forceinline__ uint32_t eval16(const char *rb, uint32_t p0, uint32_t plast, uint32_t wm16, uint32_t base,
+                                           uint32_t qh, uint32_t ql, uint32_t *keep, uint32_t &kpos) {
+  uint4 r[8];
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j)
+    if (p0 + j <= plast) r[j] = *reinterpret_cast<const uint4 *>(rb + ((p0 + j) << 4));
+  uint32_t m = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    const uint32_t rr[2] = {r[j].x, r[j].z};
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {
+      const uint32_t rl = (rr[k] - base) & 0xFFFFu;
+      m = shift_in_le_ge(m, rl, qh, rl + (rr[k] >> 16), ql);
+    }
+  }
+  m = (__brev(m) >> 16) & wm16;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    const uint32_t ii[2] = {r[j].y, r[j].w};
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {
+      keep[kpos] = ii[k];
+      kpos = min(kpos + ((m >> (2 * j + k)) & 1u), KEEP - 1u);
+    }
+  }
+  return m;
+}
+
+template <uint32_t KEEP>
+__device__ __forceinline__ uint32_t lanes_mask32(const uint2 *rec, const Win &w, uint32_t lo, uint32_t hi, uint32_t *keep) {
+  const bool nonempty = (w.fl & 1u) != 0;
+  const uint32_t al = w.a & ~1u;
+  const uint32_t b = nonempty ? w.b : al;  // (an empty window: no lane-load, no hit)
+  const uint32_t p0 = al >> 1, plast = ((b + 1u) >> 1) - 1u;  // p0 + j <= plast <=> slot al + 2j < b
+  // (the index holds at most 2^28 records when this kernel is chosen: byte offsets fit 32 bits)
+  const char *rb = reinterpret_cast<const char *>(rec);
+  const uint32_t qh = hi - w.base, ql = lo > w.base ? lo - w.base : 0u;
+  const uint32_t wm = ((1u << (b - al)) - 1u) & ~(w.a - al);  // bits [a - al, b - al); a - al is 0 or 1
+  uint32_t kpos = 0;
+  uint32_t m = 0;
+  if (b > al) m = eval16<KEEP>(rb, p0, plast, wm & 0xFFFFu, w.base, qh, ql, keep, kpos);
+  if (__any(b > al + 16u)) {
+    if (b > al + 16u) m |= eval16<KEEP>(rb, p0 + 8u, plast, wm >> 16, w.base, qh, ql, keep, kpos) << 16;
+  }
+  return m;
 }
 
 // S: every query's ids leave in ascending order (ordered by their lane while they sit in the stage).
@@ -284,8 +351,16 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
   }
 
   // ==================================== a worker wavefront ===================================================
-  uint32_t *const kept = reinterpret_cast<uint32_t *>(&s_keep[threadIdx.x * (kPKeep / 4)]);
-  uint4 *const slab = &s_keep[(threadIdx.x & ~(kWave - 1)) * (kPKeep / 4)];
+  // The thread's index, taken afresh wherever an address is derived from it: the loop below is long, and values the
+  // compiler computes once in front of it (lane * 16 as a 64-bit offset, the lane's LDS addresses) would otherwise be
+  // held — or spilled — across all of its phases.
+  auto tid = [] {
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+  };
+  auto kept_slots = [&] { return reinterpret_cast<uint32_t *>(&s_keep[tid() * (kPKeep / 4)]); };
+  auto slab_of_wave = [&] { return &s_keep[(tid() & ~(uint32_t)(kWave - 1)) * (kPKeep / 4)]; };
 
   auto query_of = [&](uint32_t t) {
     kargs_t p = fresh(ka);
@@ -294,6 +369,21 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     w.nchrom = p->v.nchrom;
     w.flt_qaux = nullptr;
     return load_query<false>(w, cs, p->a.qchrom, p->a.qlow, p->a.qhigh, q, t < p->a.ntiles && q < p->a.q_end);
+  };
+
+  auto window_of = [&](const Query &q) {
+    Win w{0u, 0u, 0u, 0u};
+    if (q.nseg) {
+      const SegDesc d = load_seg(segs + q.s0);
+      IndexView vt;  // seg_window reads the directory only
+      vt.table = fresh(ka)->v.table;
+      const Window x = seg_window(vt, d, q.lo, q.hi);
+      w.a = x.a;
+      w.b = x.b;
+      w.base = x.cell0_low;
+      w.fl = (x.span != 0 && x.b > x.a ? 1u : 0u) | ((d.shift & kSegPacked) != 0 && x.narrow ? 2u : 0u);
+    }
+    return w;
   };
 
   // The two pending slices: counted and reported, their ids in a stage each (or, unstaged, their counts), output
@@ -323,7 +413,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       const uint64_t cap = p->a.cap;
       if (cap != 0) {
         uint32_t *hits = p->a.hits;
-        for (uint32_t i = lane; i < pd.wtotal; i += kWave) {
+        for (uint32_t i = tid() & (kWave - 1); i < pd.wtotal; i += kWave) {
           const uint64_t pos = wpos0 + i;
           if (pos < cap) hits[pos] = stage[i];
         }
@@ -352,14 +442,44 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
 
   for (uint32_t it = 0;; ++it) {
     const bool live = tile < A(ntiles);
-    Replay rp;
+    int path = 0;                  // how the slice was counted (wavefront-uniform), see below
+    uint32_t qw_a = 0;             // paths 1 and 2: the window's first slot
+    uint32_t m32 = 0, lbase = 0;   // paths 1 and 2: the hit mask (bit j <-> slot (a & ~1) + j); path 1: the slab's first slot
     uint32_t cnt = 0, loff = 0, wtotal = 0;
     bool staged = false, no_ids = false;
     uint64_t lpos64 = 0;
     if (live) {
       PSTAMP(tile, 0);
       // ---- count the slice of the new tile ------------------------------------------------------------------
-      {
+      // Three ways, chosen per wavefront from the windows themselves: (1) all windows short and neighbours in the
+      // index (a position-sorted batch): their union goes through the LDS slab once; (2) all short, scattered (or only
+      // partly neighbours): every lane reads its own; (0) long windows, unpacked segments: the general enumeration
+      // counts, and the slice's ids are k_fill_slices' business (it is listed like one that overflows its stage).
+      const Win wn = window_of(qy);
+      const bool nonempty = (wn.fl & 1u) != 0;
+      const uint32_t al = wn.a & ~1u;
+      qw_a = wn.a;
+      path = 0;
+      if (!__any(nonempty && !((wn.fl & 2u) != 0 && wn.b - al < 32u))) {
+        lbase = wave_min(nonempty ? al : 0xFFFFFFFFu);
+        const bool in_slab = nonempty && wn.b - lbase <= kPKeep * (kWave / 2);
+        const uint32_t nin = (uint32_t)__popcll(__ballot(in_slab)), nne = (uint32_t)__popcll(__ballot(nonempty));
+        path = nin >= kSlabMinLanes && nin == nne ? 1 : 2;
+      }
+      no_ids = A(cap) == 0;
+      if (path == 1) {
+        const uint32_t npairs = (wave_max(nonempty ? wn.b : 0u) - lbase + 1u) >> 1;  // fits the slab; rec[] carries two spare slots
+        const uint4 *src = reinterpret_cast<const uint4 *>(fresh(ka)->v.rec) + (lbase >> 1);
+        uint4 *const slab = slab_of_wave();
+        for (uint32_t i = tid() & (kWave - 1); i < npairs; i += kWave) slab[i] = src[i];
+        wave_sync_lds();
+        const Window w{wn.a, wn.b, wn.base, 1u, true};
+        m32 = slab_mask32(slab, lbase, w, qy.lo, qy.hi, nonempty);
+        cnt = (uint32_t)__popc(m32);
+      } else if (path == 2) {
+        m32 = lanes_mask32<kPKeep>(fresh(ka)->v.rec, wn, qy.lo, qy.hi, kept_slots());
+        cnt = (uint32_t)__popc(m32);
+      } else {
         kargs_t p = fresh(ka);
         IndexView v1;
         v1.se = p->v.se;
@@ -377,16 +497,14 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         v1.flt_qaux = nullptr;
         v1.flt_iaux = nullptr;
         v1.err = nullptr;
-        cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, true>(v1, segs, qy, nullptr, 0, 0, &rp, kept,
-                                                                           nullptr, slab);
+        cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, false>(v1, segs, qy, nullptr, 0, 0, nullptr);
       }
       const uint32_t incl = wave_scan_incl(cnt);
       loff = incl - cnt;
       // (2^22 hits in one lane would overflow the 32-bit scan: such a slice is never staged and is counted in 64 bits)
       const bool huge = __any(cnt >= (1u << 22));
       wtotal = wave_last(incl);
-      no_ids = A(cap) == 0;
-      staged = !huge && (no_ids ? wtotal < 65536u : !__any(!rp.ok) && wtotal <= kPStage);
+      staged = !huge && (no_ids ? wtotal < 65536u : path != 0 && wtotal <= kPStage);
       uint64_t wt64 = wtotal;
       lpos64 = loff;
       if (huge) {
@@ -435,47 +553,29 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       stage[3 * lane] = (uint32_t)lpos64;
       stage[3 * lane + 1] = (uint32_t)(lpos64 >> 32);
       stage[3 * lane + 2] = cnt;
-    } else if (!no_ids && cnt) {
-      uint64_t mrem = rp.mask;
-      if (rp.lds && !__any((uint32_t)(rp.mask >> 32) != 0u)) {  // ... and every window is shorter than 32 slots
-        const uint2 *s2 = reinterpret_cast<const uint2 *>(slab) + (rp.al - rp.lbase);
-        uint32_t m32 = (uint32_t)rp.mask;
-        uint32_t *dst = stage + loff;
+    } else if (!no_ids && path == 1) {  // the ids are in the wavefront's slab
+      const uint2 *s2 = reinterpret_cast<const uint2 *>(slab_of_wave()) + ((qw_a & ~1u) - lbase);
+      uint32_t *dst = stage + loff;
+      while (m32) {
+        const uint32_t j = (uint32_t)__ffs((int)m32) - 1u;
+        m32 &= m32 - 1u;
+        *dst++ = s2[j].y;
+      }
+    } else if (!no_ids && path == 2) {  // the first kPKeep ids are in the lane's keep slots; a longer list re-reads the rest
+      uint32_t *dst = stage + loff;
+      const uint32_t *kslots = kept_slots();
+      const uint32_t nk = cnt < kPKeep ? cnt : kPKeep - 1u;  // (the last slot is only good while it was not the limit)
+      for (uint32_t k = 0; k < nk; ++k) {
+        dst[k] = kslots[k];
+        m32 &= m32 - 1u;
+      }
+      if (__any(m32 != 0u)) {
+        const char *rb = reinterpret_cast<const char *>(fresh(ka)->v.rec);
+        dst += nk;
         while (m32) {
           const uint32_t j = (uint32_t)__ffs((int)m32) - 1u;
           m32 &= m32 - 1u;
-          *dst++ = s2[j].y;
-        }
-      } else if (rp.lds) {  // everything is in the wavefront's slab
-        const uint2 *s2 = reinterpret_cast<const uint2 *>(slab) + (rp.al - rp.lbase);
-        for (uint32_t k = 0; k < cnt; ++k) {
-          const uint32_t j = (uint32_t)__ffsll((long long)mrem) - 1u;
-          mrem &= mrem - 1;
-          stage[loff + k] = s2[j].y;
-        }
-      } else {
-        const uint32_t nk = rp.kept ? (cnt < kPKeep ? cnt : kPKeep) : 0u;
-        for (uint32_t k = 0; k < nk; ++k) {
-          stage[loff + k] = kept[k];
-          mrem &= mrem - 1;
-        }
-        if (nk < cnt) {  // the rest is re-read next to its record
-          kargs_t p = fresh(ka);
-          const uint2 *rec = p->v.rec;
-          const uint32_t *idv = p->v.id;
-          for (uint32_t k = nk; k < cnt; k += kPGather) {
-            uint32_t ids[kPGather];
-#pragma unroll
-            for (uint32_t i = 0; i < kPGather; ++i)
-              if (k + i < cnt) {
-                const uint32_t j = (uint32_t)__ffsll((long long)mrem) - 1u;
-                mrem &= mrem - 1;
-                ids[i] = rp.packed ? rec[rp.al + j].y : idv[rp.al + j];
-              }
-#pragma unroll
-            for (uint32_t i = 0; i < kPGather; ++i)
-              if (k + i < cnt) stage[loff + k + i] = ids[i];
-          }
+          *dst++ = *reinterpret_cast<const uint32_t *>(rb + ((((qw_a & ~1u) + j) << 3) + 4u));
         }
       }
     }
@@ -499,7 +599,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         for (uint32_t k = 0; k < 8u; ++k)
           if (k < cnt) stage[loff + rank[k]] = x[k];
       } else if (cnt > 8u) {
-        uint32_t *const tmp = reinterpret_cast<uint32_t *>(slab);
+        uint32_t *const tmp = reinterpret_cast<uint32_t *>(slab_of_wave());
         rank_sort_list<8>(stage, tmp, loff, cnt);
         for (uint32_t k = 0; k < cnt; ++k) stage[loff + k] = tmp[loff + k];
       }
@@ -516,10 +616,12 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
 // (k_query<Fill>'s, wavefront-cooperative windows included). One work item = one slice (64 queries, one wavefront);
 // the grid is fixed and strides over the items, so the launch needs no host knowledge of the list; the last workgroup
 // to finish clears the count.
+template <bool S>
 __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs a) {
   __shared__ SegDesc s_seg[kLdsSegs];
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ uint32_t s_last;
+  __shared__ uint32_t s_sort[S ? kQWaves : 1][S ? kSortLds / 2 : 1];
   const uint32_t *todo = reinterpret_cast<const uint32_t *>(a.ws + kWsStatus + kFMaxGroups + kFMaxTiles);
   const uint32_t n =
       __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.ws + kWsTodo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -536,10 +638,21 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
     const Query qy = load_query<false>(v, cs, a.qchrom, a.qlow, a.qhigh, q, valid);
     const uint64_t pos = valid ? a.offsets[q] : 0;
     (void)enumerate_hits<Mode::Fill, false>(v, segs, qy, a.hits, pos, a.cap, nullptr);
+    if (S) {
+      // ascending ids were asked for: the slice's 64 lists are ordered here, where they were just written (asking for
+      // the conditional k_sort_hits pass instead would send it over the whole batch for the sake of a few slices)
+      wave_sync_mem();
+      uint64_t o0 = pos, o1;
+      if (valid) {
+        o1 = a.offsets[q + 1];
+      } else {
+        o0 = o1 = a.offsets[a.q_end];
+      }
+      o0 = o0 < a.cap ? o0 : a.cap;
+      o1 = o1 < a.cap ? o1 : a.cap;
+      wave_sort_lists<kSortLds / 2, kRankBlock, false>(s_sort[wave], o0, o1, a.hits, (int)lane);
+    }
   }
-  // these lists are in index order: the conditional k_sort_hits behind this kernel orders them if ascending ids were asked for
-  if (a.seq != 0 && threadIdx.x == 0)
-    __hip_atomic_store(reinterpret_cast<uint32_t *>(a.ws + kWsNeedSort), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // every workgroup that saw a non-empty list reports; the last one clears the list for the next call
   __syncthreads();
   if (threadIdx.x == 0)
@@ -559,6 +672,7 @@ bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bo
   const char *env = std::getenv("BIVX_PIPE");
   const int mode = env ? std::atoi(env) : 1;
   if (!mode || unordered || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
+  if (v.nslots > (1u << 28)) return false;  // (32-bit byte offsets into the records, lanes_mask32)
   // batches of a few tiles per resident workgroup gain nothing from a pipeline that has to fill and drain
   // (config 2, 977 tiles: 60 us against 55 for k_query_fused)
   if (q < (size_t)4 * 512 * kPTile && mode != 2) return false;
@@ -588,7 +702,10 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
     hipLaunchKernelGGL(k_query_pipe<true>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   else
     hipLaunchKernelGGL(k_query_pipe<false>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
-  hipLaunchKernelGGL(k_fill_slices, dim3(256), dim3(kQThreads), 0, s, v, a);
+  if (sort_seq)
+    hipLaunchKernelGGL(k_fill_slices<true>, dim3(256), dim3(kQThreads), 0, s, v, a);
+  else
+    hipLaunchKernelGGL(k_fill_slices<false>, dim3(256), dim3(kQThreads), 0, s, v, a);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
