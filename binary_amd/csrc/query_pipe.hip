@@ -102,14 +102,16 @@ __device__ __forceinline__ void lds_store(uint32_t *p, uint32_t x) {
 }
 // (uniform per wavefront: every lane polls the same word)
 __device__ __forceinline__ void lds_wait_eq(const uint32_t *p, uint32_t x) {
-  while (lds_load(p) != x) __builtin_amdgcn_s_sleep(1);
+  // (polls cost issue slots the other wavefronts of the SIMD could use: a wait of a few microseconds is not polled
+  // every sixty nanoseconds)
+  while (lds_load(p) != x) __builtin_amdgcn_s_sleep(4);
 }
 
 // A query's candidate window, worked out ahead of the counting (bucket directory probe): slots [a, b), the coordinate of
 // its first cell, and what kind it is.
 struct Win {
   uint32_t a, b, base;
-  uint32_t fl;  // 1: not empty; 2: packed records decodable (a packed segment's window over at most 65536 coordinates)
+  uint32_t fl;  // 1: the query reaches the segment.s cells (the window is non-empty if also b > a); 2: packed records decodable
 };
 
 // Hit mask of a window shorter than 32 slots, read by its own lane (queries in arbitrary order: the windows of a
@@ -147,7 +149,7 @@ __device__ __forceinline__ uint32_t eval16(const char *rb, uint32_t p0, uint32_t
     const uint32_t ii[2] = {r[j].y, r[j].w};
 #pragma unroll
     for (uint32_t k = 0; k < 2; ++k) {
-      keep[kpos] = ii[k];
+      keep[kpos * kWave] = ii[k];  // (slot k of lane l is word k * 64 + l of the wavefront's region: no bank conflict)
       kpos = min(kpos + ((m >> (2 * j + k)) & 1u), KEEP - 1u);
     }
   }
@@ -155,8 +157,8 @@ __device__ __forceinline__ uint32_t eval16(const char *rb, uint32_t p0, uint32_t
 }
 
 template <uint32_t KEEP>
-__device__ __forceinline__ uint32_t lanes_mask32(const uint2 *rec, const Win &w, uint32_t lo, uint32_t hi, uint32_t *keep) {
-  const bool nonempty = (w.fl & 1u) != 0;
+__device__ __forceinline__ uint32_t lanes_mask32(const uint2 *rec, const Win &w, bool nonempty, uint32_t lo, uint32_t hi,
+                                                 uint32_t *keep) {
   const uint32_t al = w.a & ~1u;
   const uint32_t b = nonempty ? w.b : al;  // (an empty window: no lane-load, no hit)
   const uint32_t p0 = al >> 1, plast = ((b + 1u) >> 1) - 1u;  // p0 + j <= plast <=> slot al + 2j < b
@@ -359,7 +361,11 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     asm volatile("" : "+v"(t));
     return t;
   };
-  auto kept_slots = [&] { return reinterpret_cast<uint32_t *>(&s_keep[tid() * (kPKeep / 4)]); };
+  // keep slot k of a lane: kept_slots()[k * kWave] (the wavefront's 512 words, transposed; the same words are its slab)
+  auto kept_slots = [&] {
+    const uint32_t t = tid();
+    return reinterpret_cast<uint32_t *>(&s_keep[(t & ~(uint32_t)(kWave - 1)) * (kPKeep / 4)]) + (t & (kWave - 1));
+  };
   auto slab_of_wave = [&] { return &s_keep[(tid() & ~(uint32_t)(kWave - 1)) * (kPKeep / 4)]; };
 
   auto query_of = [&](uint32_t t) {
@@ -371,17 +377,25 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     return load_query<false>(w, cs, p->a.qchrom, p->a.qlow, p->a.qhigh, q, t < p->a.ntiles && q < p->a.q_end);
   };
 
+  // The bucket-directory probe of a query (seg_window's arithmetic, query_device.h), issued and NOT waited for: a and b
+  // are the two directory words on their way; `fl` says whether the query touches the segment's cells at all (1) and
+  // whether the window's packed records are decodable (2). The window is non-empty if fl & 1 and b > a.
   auto window_of = [&](const Query &q) {
     Win w{0u, 0u, 0u, 0u};
     if (q.nseg) {
       const SegDesc d = load_seg(segs + q.s0);
-      IndexView vt;  // seg_window reads the directory only
-      vt.table = fresh(ka)->v.table;
-      const Window x = seg_window(vt, d, q.lo, q.hi);
-      w.a = x.a;
-      w.b = x.b;
-      w.base = x.cell0_low;
-      w.fl = (x.span != 0 && x.b > x.a ? 1u : 0u) | ((d.shift & kSegPacked) != 0 && x.narrow ? 2u : 0u);
+      const uint32_t x = q.lo > d.maxlen ? q.lo - d.maxlen : 0u;
+      if (!(q.hi < d.base || x > d.last || q.hi < x)) {
+        const uint32_t sh = d.shift & 31u;
+        const uint32_t ca = x <= d.base ? 0u : (x - d.base) >> sh;
+        const uint32_t cb = q.hi >= d.last ? d.ncell : ((q.hi - d.base) >> sh) + 1u;
+        // (32-bit byte offsets: the directory has fewer entries than the index has records, at most 2^28 here)
+        const char *t = reinterpret_cast<const char *>(fresh(ka)->v.table);
+        w.a = *reinterpret_cast<const uint32_t *>(t + ((d.table_off + ca) << 2));
+        w.b = *reinterpret_cast<const uint32_t *>(t + ((d.table_off + cb) << 2));
+        w.base = d.base + (ca << sh);
+        w.fl = 1u | ((d.shift & kSegPacked) != 0 && ((uint64_t)(cb - ca) << sh) <= 65536ull ? 2u : 0u);
+      }
     }
     return w;
   };
@@ -438,7 +452,17 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
 
   lds_wait_eq(&s_slot[0].gen_ticket, 1u);
   uint32_t tile = __builtin_amdgcn_readfirstlane(s_slot[0].tile);
-  Query qy = query_of(tile);
+  // What a lane carries from one iteration to the next: its query of the coming tile and that query's directory
+  // probe, both issued an iteration ahead (the queries when the ticket comes in, the probe when they have arrived —
+  // behind the flush — so that its round trip runs under the id layout).
+  uint32_t qlo, qhi;
+  Win wn;
+  {
+    const Query q0 = query_of(tile);
+    qlo = q0.lo;
+    qhi = q0.hi;
+    wn = window_of(q0);
+  }
 
   for (uint32_t it = 0;; ++it) {
     const bool live = tile < A(ntiles);
@@ -455,8 +479,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       // index (a position-sorted batch): their union goes through the LDS slab once; (2) all short, scattered (or only
       // partly neighbours): every lane reads its own; (0) long windows, unpacked segments: the general enumeration
       // counts, and the slice's ids are k_fill_slices' business (it is listed like one that overflows its stage).
-      const Win wn = window_of(qy);
-      const bool nonempty = (wn.fl & 1u) != 0;
+      const bool nonempty = (wn.fl & 1u) != 0 && wn.b > wn.a;
       const uint32_t al = wn.a & ~1u;
       qw_a = wn.a;
       path = 0;
@@ -474,10 +497,10 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         for (uint32_t i = tid() & (kWave - 1); i < npairs; i += kWave) slab[i] = src[i];
         wave_sync_lds();
         const Window w{wn.a, wn.b, wn.base, 1u, true};
-        m32 = slab_mask32(slab, lbase, w, qy.lo, qy.hi, nonempty);
+        m32 = slab_mask32(slab, lbase, w, qlo, qhi, nonempty);
         cnt = (uint32_t)__popc(m32);
       } else if (path == 2) {
-        m32 = lanes_mask32<kPKeep>(fresh(ka)->v.rec, wn, qy.lo, qy.hi, kept_slots());
+        m32 = lanes_mask32<kPKeep>(fresh(ka)->v.rec, wn, nonempty, qlo, qhi, kept_slots());
         cnt = (uint32_t)__popc(m32);
       } else {
         kargs_t p = fresh(ka);
@@ -497,6 +520,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         v1.flt_qaux = nullptr;
         v1.flt_iaux = nullptr;
         v1.err = nullptr;
+        const Query qy = query_of(tile);  // (rare: the query is fetched again rather than carried)
         cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, false>(v1, segs, qy, nullptr, 0, 0, nullptr);
       }
       const uint32_t incl = wave_scan_incl(cnt);
@@ -544,6 +568,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       break;
     }
     PSTAMP(tile, 3);
+    const Win nwn = window_of(nqy);  // (its two loads are consumed at the top of the next iteration)
 
     // ---- lay the new slice's ids out in the stage, back to back as they will sit in the output -------------------
     pb = pa;
@@ -566,7 +591,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       const uint32_t *kslots = kept_slots();
       const uint32_t nk = cnt < kPKeep ? cnt : kPKeep - 1u;  // (the last slot is only good while it was not the limit)
       for (uint32_t k = 0; k < nk; ++k) {
-        dst[k] = kslots[k];
+        dst[k] = kslots[k * kWave];
         m32 &= m32 - 1u;
       }
       if (__any(m32 != 0u)) {
@@ -607,7 +632,9 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     wave_sync_lds();
     PSTAMP(tile, 4);
     tile = ntile;
-    qy = nqy;
+    qlo = nqy.lo;
+    qhi = nqy.hi;
+    wn = nwn;
   }
 #undef A
 }
