@@ -304,6 +304,43 @@ __device__ __forceinline__ uint32_t slab_mask32(const uint4 *slab, uint32_t lbas
   return m & wm;
 }
 
+// The same for windows of up to 64 slots (kLight): chunks 0..3 build the low word, chunks 4..7 the high word.
+__device__ __forceinline__ uint64_t slab_mask64(const uint4 *slab, uint32_t lbase, const Window &w, uint32_t lo,
+                                                uint32_t hi, bool nonempty) {
+  const uint32_t al = w.a & ~1u;
+  const uint32_t nch = wave_max(nonempty ? (w.b - al + 7u) >> 3 : 0u);
+  if (nch == 0) return 0ull;
+  const uint4 *sp = slab + (nonempty ? (al - lbase) >> 1 : 0u);
+  const uint32_t base = w.cell0_low;
+  const uint32_t qh = hi - base, ql = lo > base ? lo - base : 0u;
+  uint32_t mw[2] = {0u, 0u};
+#pragma unroll
+  for (uint32_t h = 0; h < 2; ++h) {
+    const uint32_t c0 = 4u * h, c1 = nch < c0 + 4u ? nch : c0 + 4u;
+    if (c1 <= c0) break;
+    uint32_t m = 0;
+#pragma unroll 1
+    for (uint32_t c = c0; c < c1; ++c) {
+      uint4 r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = sp[4 * c + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t rr[2] = {r[j].x, r[j].z};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t rl = (rr[e] - base) & 0xFFFFu;
+          m = shift_in_le_ge(m, rl, qh, rl + (rr[e] >> 16), ql);
+        }
+      }
+    }
+    mw[h] = __brev(m) >> (32u - 8u * (c1 - c0));
+  }
+  const uint32_t n = w.b - al;  // <= 64
+  const uint64_t wm = nonempty ? ((n >= 64u ? ~0ull : (1ull << n) - 1ull) & ~(uint64_t)(w.a - al)) : 0ull;
+  return ((uint64_t)mw[0] | (uint64_t)mw[1] << 32) & wm;
+}
+
 // First slot in [a, b) whose low is >= x (b if there is none), found by the whole wavefront: a 64-ary search — the
 // 64 lanes probe 64 evenly spaced slots, one __ballot tells which gap holds the answer, repeat. Used to trim long
 // candidate windows (many intervals starting inside one directory cell) to the slots whose low lies in
@@ -427,16 +464,18 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       }
       in_slab = in_slab && slab_on;
       if (!MS && !F && slab_on && rp) {
-        const bool shortw = in_slab && w.b - (w.a & ~1u) < 32u;
-        if (!__any(nonempty && !shortw)) {
-          const uint32_t m = slab_mask32(slab, lbase, w, lo, hi, nonempty);
+        // every window of the wavefront is in the slab (hence light and packed): the branch-free evaluation
+        if (!__any(nonempty && !in_slab)) {
+          const bool short32 = !__any(nonempty && w.b - (w.a & ~1u) >= 32u);
+          const uint64_t m = short32 ? (uint64_t)slab_mask32(slab, lbase, w, lo, hi, nonempty)
+                                     : slab_mask64(slab, lbase, w, lo, hi, nonempty);
           rp->al = w.a & ~1u;
           rp->mask = m;
           rp->packed = true;
           rp->lds = true;
           rp->lbase = lbase;
           rp->nrec = 1;
-          return (uint32_t)__popc(m);
+          return (uint32_t)__popcll(m);
         }
       }
     }
