@@ -15,8 +15,9 @@ constexpr uint64_t kStValid = 1ull << 63;
 // workspace words: the two counters and the status array sit on cache lines of their own, so that the atomics
 // on the counters do not queue behind (or in front of) the sweeps' polls of the first status words
 constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsNeedSort = 24, kWsTodo = 26, kWsTodoDone = 28,
-                   kWsStatus = 32;
+                   kWsOrder = 30, kWsStatus = 32;
 // ws[kWsTodo]: tiles the pipelined kernel left for k_fill_tiles (count); their numbers follow the status words
+// ws[kWsOrder]: sequence number of the last launch whose batch k_probe_order found position-sorted (query_pipe.hip)
 // ws[kWsNeedSort]: sequence number of the last launch that left lists for k_sort_hits to order (never cleared:
 // every launch carries a fresh number)
 constexpr uint32_t kDoneShift = 44;  // unordered output: ws[kWsDone] = departures << 44 | ids reserved by this launch

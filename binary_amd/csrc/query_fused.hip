@@ -77,7 +77,13 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
                                                            uint32_t *__restrict__ hits, uint64_t cap,
                                                            uint64_t *__restrict__ ws, int flags,
                                                            uint32_t *__restrict__ counts,
-                                                           uint64_t *__restrict__ total_out, uint32_t seq) {
+                                                           uint64_t *__restrict__ total_out, uint32_t seq,
+                                                           uint32_t skip_seq) {
+  // launched behind k_query_pipe_dense (query_pipe.hip): that kernel did the launch's work if the order probe
+  // left this number
+  if (skip_seq != 0 && __hip_atomic_load(reinterpret_cast<const uint32_t *>(ws + kWsOrder), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT) == skip_seq)
+    return;
   const bool self_clean = (flags & kFlagSelfClean) != 0;
   __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
   __shared__ uint2 s_cs[LDS_DESC ? kLdsChroms : 1];
@@ -454,8 +460,11 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
   // the common case (one segment per chromosome, no filter, index order, few ids per query) has a pipelined kernel
   // with tiles of its own size
   const bool use_pipe = pipe_eligible(v, q, cap, sort_ids, unordered);
+  // ... and so has the case of many ids per query if the batch is position-sorted, which a device-side probe finds out:
+  // both kernels are launched, one of them returns at once
+  const bool try_dense = !use_pipe && pipe_dense_eligible(v, q, cap, sort_ids, unordered);
   size_t per_launch = (size_t)max_tiles * kFTile;
-  if (use_pipe) {
+  if (use_pipe || try_dense) {
     const size_t pp = pipe_queries_per_launch() / kFMaxTiles * max_tiles;
     per_launch = pp;
   }
@@ -466,8 +475,9 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
     const size_t tile_q = use_pipe ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
     const unsigned tiles = (unsigned)((q1 - q0 + tile_q - 1) / tile_q);
+    const size_t tile_small = use_pipe || try_dense ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
     if (!self_clean && !unordered)
-      BIVX_HIP(hipMemsetAsync(d_ws, 0, ((size_t)tiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
+      BIVX_HIP(hipMemsetAsync(d_ws, 0, ((q1 - q0 + tile_small - 1) / tile_small + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
     const dim3 grid(tiles), block(kFThreads);
     const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
     // BIVX_PREFIX_WAIT_LOG2 (tests): bound of a prefix wait as log2 of 10 ns ticks; 1 makes every wait that is not
@@ -485,6 +495,12 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     static std::atomic<uint32_t> launch_seq{1};
     uint32_t seq = launch_seq.fetch_add(1);
     if (seq == 0) seq = launch_seq.fetch_add(1);  // 0 is what a cleared workspace holds
+    uint32_t skip_seq = 0;
+    if (try_dense) {
+      if (int rc = launch_query_pipe_dense(v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, flags, seq, s))
+        return rc;
+      skip_seq = seq;
+    }
     if (use_pipe) {
       if (int rc = launch_query_pipe(v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, flags,
                                      sort_ids ? seq : 0u, s))
@@ -492,7 +508,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     } else {
 #define BIVX_LAUNCH_FUSED_V(L, FL, SO, MSV, UV)                                                               \
   hipLaunchKernelGGL((k_query_fused<L, FL, SO, MSV, UV>), grid, block, 0, s, v, d_qchrom, d_qlow, d_qhigh, q0, \
-                     q1, d_offsets, d_hits, cap, ws, flags, d_counts, d_total, seq)
+                     q1, d_offsets, d_hits, cap, ws, flags, d_counts, d_total, seq, skip_seq)
 #define BIVX_LAUNCH_FUSED(L, FL, SO)                       \
   if (unordered) {                                         \
     if (v.max_segs > 1)                                    \

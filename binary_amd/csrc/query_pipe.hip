@@ -175,13 +175,158 @@ __device__ __forceinline__ uint32_t lanes_mask32(const uint2 *rec, const Win &w,
   return m;
 }
 
+#define A(f) (fresh(ka)->a.f)
+
+// The service wavefront of a pipelined workgroup (k_query_pipe and k_query_pipe_dense): tickets, published totals, the
+// sweeps over the earlier tiles, the workers' bases — everything that talks to other workgroups.
+__device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, int lane) {
+  // ================================ the service wavefront ================================================
+  PrefixCtx pc;
+  {
+    kargs_t p = fresh(ka);
+    pc.group = p->a.ws + kWsStatus;
+    pc.status = pc.group + kFMaxGroups;
+    pc.ntiles = p->a.ntiles;
+    const uint32_t wl = ((uint32_t)p->a.flags >> kFlagWaitShift) & 0xFFu;
+    pc.wait_ticks = 1ull << (wl ? wl : kWaitLog2Default);
+    pc.err = p->v.err;
+  }
+  // A polled state machine over the workgroup's tiles, in the order they were drawn (iteration numbers):
+  //   drawn:     tickets handed out so far. Ticket k+1 is drawn when the first worker has reported on tile k (its
+  //              queries can then be fetched while the stragglers finish), never earlier: a ticket held by a busy
+  //              workgroup delays that tile's published total, and every later tile's sweep waits for it.
+  //   published: tiles whose total is out (needs the fifteen totals);   grouped: ... whose group word, if it is the
+  //   64th tile of a group, is out (needs the group's earlier tiles);   swept: ... whose first output position the
+  //   workers have (needs every earlier tile of the launch). None of the three waits inside: a sweep that finds a
+  //   word missing is simply tried again on the next pass, so one slow predecessor never holds a ticket back.
+  uint32_t drawn = 0, published = 0, grouped = 0, swept = 0;
+  uint32_t last_tile = 0;   // ticket of the newest drawn tile
+  bool drawing = true;      // no ticket beyond the batch yet
+  uint64_t stuck_since = 0; // when the oldest unswept tile's sweep was first found blocked
+  const bool flat = pc.ntiles <= kFlatTiles;
+  for (;;) {
+    bool progress = false;
+    // ---- a ticket ----
+    if (drawing && drawn - swept < kRing) {
+      bool want = drawn == 0;
+#ifdef BIVX_TICKET_EARLY   // experiment: a whole counting phase ahead (when every worker has begun the tile before)
+      if (!want) want = drawn == 1 || lds_load(&s_slot[(drawn - 2) % kRing].arrived) == (uint32_t)kWorkers;
+#else
+      if (!want) want = lds_load(&s_slot[(drawn - 1) % kRing].arrived) != 0;
+#endif
+      TileSlot &sl = s_slot[drawn % kRing];
+      // (the slot's last user was iteration drawn - kRing: swept, but every worker must also be through with it)
+      if (want && (drawn < kRing || lds_load(&sl.flushed) == (uint32_t)kWorkers)) {
+        uint32_t tile = 0;
+        if (lane == 0) {
+          tile = atomicAdd(reinterpret_cast<unsigned int *>(A(ws) + kWsTicket), 1u);
+          sl.arrived = 0;
+          sl.flushed = 0;
+          sl.tile = tile;
+          lds_store(&sl.gen_ticket, drawn + 1);
+        }
+        last_tile = __builtin_amdgcn_readfirstlane(tile);
+        // Every workgroup draws exactly one ticket beyond the batch, so none can reach ntiles + gridDim.x unless
+        // the counter was not zero when the launch began (a launch that died half-way, a caller workspace that was
+        // not cleared): then tiles were skipped and nothing this launch wrote can be trusted. Say so.
+        if (last_tile >= pc.ntiles + gridDim.x && lane == 0) raise_error(pc.err, kErrWorkspace);
+        if (last_tile >= pc.ntiles) drawing = false;  // the workers see it, flush what is pending and leave
+        ++drawn;
+        progress = true;
+      }
+    }
+    const uint32_t real = drawing ? drawn : drawn - 1;  // tiles of the batch among the drawn ones
+    // ---- publish ----
+    if (published < real) {
+      TileSlot &ps = s_slot[published % kRing];
+      if (lds_load(&ps.arrived) == (uint32_t)kWorkers) {
+        const uint64_t mine = lane < kWorkers ? ps.wsum[lane] : 0ull;
+        uint64_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          const uint64_t o = __shfl_up((unsigned long long)incl, d, kWave);
+          if (lane >= d) incl += o;
+        }
+        if (lane < kWorkers) ps.wbase[lane] = incl - mine;
+        const uint64_t total = __shfl((unsigned long long)incl, kWorkers - 1, kWave);
+        if (lane == 0) {
+          ps.base = total;  // parked here until the sweep replaces it with the tile's first position
+          st_status(&pc.status[ps.tile], kStValid | total);
+        }
+        ++published;
+        progress = true;
+      }
+    }
+    // ---- the group word of a group's 64th tile ----
+    if (grouped < published) {
+      TileSlot &gs = s_slot[grouped % kRing];
+      const uint32_t t = gs.tile;
+      if (flat || (t & 63u) != 63u) {
+        ++grouped;
+        progress = true;
+      } else {
+        uint64_t in_group = 0;
+        if (try_sum_in_group(pc, t, lane, in_group)) {
+          if (lane == 0) st_status(&pc.group[t >> 6], kStValid | (in_group + gs.base));
+          ++grouped;
+          progress = true;
+        }
+      }
+    }
+    // ---- sweep ----
+    if (swept < grouped) {
+      TileSlot &ss = s_slot[swept % kRing];
+      uint64_t sum = 0;
+      bool ok = try_tiles_before(pc, ss.tile, lane, sum);
+      if (!ok) {
+        // bounded by wall time: a device that stopped making progress fails the call instead of hanging it
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();
+        if (stuck_since == 0) stuck_since = now;
+        else if (now - stuck_since > pc.wait_ticks) {
+          if (lane == 0) raise_error(pc.err, kErrTimeout);
+          ok = true;  // go on with a wrong prefix; no entry point lets the call pass as success
+        }
+      }
+      if (ok) {
+        if (lane == 0) {
+          const size_t qb = A(q_begin);
+          ss.base = sum + (qb ? A(offsets)[qb] : 0ull);
+        }
+        lds_store(&ss.gen_base, swept + 1);  // (every lane stores the same word, after lane 0's base)
+        ++swept;
+        stuck_since = 0;
+        progress = true;
+      }
+    }
+    if (!drawing && swept == drawn - 1) break;
+    if (!progress) __builtin_amdgcn_s_sleep(2);
+  }
+  // self-cleaning workspace: every service wavefront bumps `done` when its sweeps are over and its last ticket is
+  // drawn; the one that sees gridDim.x - 1 knows nobody touches the words any more and zeroes them for the next
+  // launch (the list of slices for k_fill_slices stays: that kernel clears its count).
+  if (A(flags) & kFlagSelfClean) {
+    uint64_t *ws = A(ws);
+    uint32_t last = 0;
+    if (lane == 0) last = atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (__shfl(last, 0, kWave)) {
+      for (uint32_t t = (uint32_t)lane; t < pc.ntiles; t += kWave) {
+        pc.status[t] = 0;
+        if (t < (pc.ntiles + kWave - 1) / kWave) pc.group[t] = 0;
+      }
+      if (lane == 0) {
+        ws[kWsTicket] = 0;
+        ws[kWsDone] = 0;
+      }
+    }
+  }
+}
+
 // S: every query's ids leave in ascending order (ordered by their lane while they sit in the stage).
 template <bool S>
 __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, PipeArgs a_in) {
   (void)v_in;
   (void)a_in;
   kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-#define A(f) (fresh(ka)->a.f)
   __shared__ SegDesc s_seg[kLdsSegs];
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ TileSlot s_slot[kRing];
@@ -210,145 +355,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
   const uint2 *const cs = s_cs;
 
   if (wave == kWorkers) {
-    // ================================ the service wavefront ================================================
-    PrefixCtx pc;
-    {
-      kargs_t p = fresh(ka);
-      pc.group = p->a.ws + kWsStatus;
-      pc.status = pc.group + kFMaxGroups;
-      pc.ntiles = p->a.ntiles;
-      const uint32_t wl = ((uint32_t)p->a.flags >> kFlagWaitShift) & 0xFFu;
-      pc.wait_ticks = 1ull << (wl ? wl : kWaitLog2Default);
-      pc.err = p->v.err;
-    }
-    // A polled state machine over the workgroup's tiles, in the order they were drawn (iteration numbers):
-    //   drawn:     tickets handed out so far. Ticket k+1 is drawn when the first worker has reported on tile k (its
-    //              queries can then be fetched while the stragglers finish), never earlier: a ticket held by a busy
-    //              workgroup delays that tile's published total, and every later tile's sweep waits for it.
-    //   published: tiles whose total is out (needs the fifteen totals);   grouped: ... whose group word, if it is the
-    //   64th tile of a group, is out (needs the group's earlier tiles);   swept: ... whose first output position the
-    //   workers have (needs every earlier tile of the launch). None of the three waits inside: a sweep that finds a
-    //   word missing is simply tried again on the next pass, so one slow predecessor never holds a ticket back.
-    uint32_t drawn = 0, published = 0, grouped = 0, swept = 0;
-    uint32_t last_tile = 0;   // ticket of the newest drawn tile
-    bool drawing = true;      // no ticket beyond the batch yet
-    uint64_t stuck_since = 0; // when the oldest unswept tile's sweep was first found blocked
-    const bool flat = pc.ntiles <= kFlatTiles;
-    for (;;) {
-      bool progress = false;
-      // ---- a ticket ----
-      if (drawing && drawn - swept < kRing) {
-        bool want = drawn == 0;
-#ifdef BIVX_TICKET_EARLY   // experiment: a whole counting phase ahead (when every worker has begun the tile before)
-        if (!want) want = drawn == 1 || lds_load(&s_slot[(drawn - 2) % kRing].arrived) == (uint32_t)kWorkers;
-#else
-        if (!want) want = lds_load(&s_slot[(drawn - 1) % kRing].arrived) != 0;
-#endif
-        TileSlot &sl = s_slot[drawn % kRing];
-        // (the slot's last user was iteration drawn - kRing: swept, but every worker must also be through with it)
-        if (want && (drawn < kRing || lds_load(&sl.flushed) == (uint32_t)kWorkers)) {
-          uint32_t tile = 0;
-          if (lane == 0) {
-            tile = atomicAdd(reinterpret_cast<unsigned int *>(A(ws) + kWsTicket), 1u);
-            sl.arrived = 0;
-            sl.flushed = 0;
-            sl.tile = tile;
-            lds_store(&sl.gen_ticket, drawn + 1);
-          }
-          last_tile = __builtin_amdgcn_readfirstlane(tile);
-          // Every workgroup draws exactly one ticket beyond the batch, so none can reach ntiles + gridDim.x unless
-          // the counter was not zero when the launch began (a launch that died half-way, a caller workspace that was
-          // not cleared): then tiles were skipped and nothing this launch wrote can be trusted. Say so.
-          if (last_tile >= pc.ntiles + gridDim.x && lane == 0) raise_error(pc.err, kErrWorkspace);
-          if (last_tile >= pc.ntiles) drawing = false;  // the workers see it, flush what is pending and leave
-          ++drawn;
-          progress = true;
-        }
-      }
-      const uint32_t real = drawing ? drawn : drawn - 1;  // tiles of the batch among the drawn ones
-      // ---- publish ----
-      if (published < real) {
-        TileSlot &ps = s_slot[published % kRing];
-        if (lds_load(&ps.arrived) == (uint32_t)kWorkers) {
-          const uint64_t mine = lane < kWorkers ? ps.wsum[lane] : 0ull;
-          uint64_t incl = mine;
-#pragma unroll
-          for (int d = 1; d < 16; d <<= 1) {
-            const uint64_t o = __shfl_up((unsigned long long)incl, d, kWave);
-            if (lane >= d) incl += o;
-          }
-          if (lane < kWorkers) ps.wbase[lane] = incl - mine;
-          const uint64_t total = __shfl((unsigned long long)incl, kWorkers - 1, kWave);
-          if (lane == 0) {
-            ps.base = total;  // parked here until the sweep replaces it with the tile's first position
-            st_status(&pc.status[ps.tile], kStValid | total);
-          }
-          ++published;
-          progress = true;
-        }
-      }
-      // ---- the group word of a group's 64th tile ----
-      if (grouped < published) {
-        TileSlot &gs = s_slot[grouped % kRing];
-        const uint32_t t = gs.tile;
-        if (flat || (t & 63u) != 63u) {
-          ++grouped;
-          progress = true;
-        } else {
-          uint64_t in_group = 0;
-          if (try_sum_in_group(pc, t, lane, in_group)) {
-            if (lane == 0) st_status(&pc.group[t >> 6], kStValid | (in_group + gs.base));
-            ++grouped;
-            progress = true;
-          }
-        }
-      }
-      // ---- sweep ----
-      if (swept < grouped) {
-        TileSlot &ss = s_slot[swept % kRing];
-        uint64_t sum = 0;
-        bool ok = try_tiles_before(pc, ss.tile, lane, sum);
-        if (!ok) {
-          // bounded by wall time: a device that stopped making progress fails the call instead of hanging it
-          const uint64_t now = __builtin_amdgcn_s_memrealtime();
-          if (stuck_since == 0) stuck_since = now;
-          else if (now - stuck_since > pc.wait_ticks) {
-            if (lane == 0) raise_error(pc.err, kErrTimeout);
-            ok = true;  // go on with a wrong prefix; no entry point lets the call pass as success
-          }
-        }
-        if (ok) {
-          if (lane == 0) {
-            const size_t qb = A(q_begin);
-            ss.base = sum + (qb ? A(offsets)[qb] : 0ull);
-          }
-          lds_store(&ss.gen_base, swept + 1);  // (every lane stores the same word, after lane 0's base)
-          ++swept;
-          stuck_since = 0;
-          progress = true;
-        }
-      }
-      if (!drawing && swept == drawn - 1) break;
-      if (!progress) __builtin_amdgcn_s_sleep(2);
-    }
-    // self-cleaning workspace: every service wavefront bumps `done` when its sweeps are over and its last ticket is
-    // drawn; the one that sees gridDim.x - 1 knows nobody touches the words any more and zeroes them for the next
-    // launch (the list of slices for k_fill_slices stays: that kernel clears its count).
-    if (A(flags) & kFlagSelfClean) {
-      uint64_t *ws = A(ws);
-      uint32_t last = 0;
-      if (lane == 0) last = atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsDone), 1u) == gridDim.x - 1 ? 1u : 0u;
-      if (__shfl(last, 0, kWave)) {
-        for (uint32_t t = (uint32_t)lane; t < pc.ntiles; t += kWave) {
-          pc.status[t] = 0;
-          if (t < (pc.ntiles + kWave - 1) / kWave) pc.group[t] = 0;
-        }
-        if (lane == 0) {
-          ws[kWsTicket] = 0;
-          ws[kWsDone] = 0;
-        }
-      }
-    }
+    pipe_service_wave(ka, s_slot, lane);
     return;
   }
 
@@ -636,8 +643,315 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     qhi = nqy.hi;
     wn = nwn;
   }
-#undef A
+
 }
+
+// ---- the same pipeline for MANY ids per query, on position-sorted batches ----------------------------------------------
+// (config 5: an index overlapped with itself in its own order, 17 ids per query — a wavefront's 64 lists are ~1100 ids
+// and fit no stage.) What a pending slice keeps for two iterations is not its ids but what regenerates them: every
+// lane's hit mask (64 bits), the window's first slot and the slab's bounds. When the slice's base is known the slab —
+// the union of the wavefront's windows, read for counting two iterations ago and still in L2 — is fetched again
+// (issued right after counting, consumed here) and the ids go from it through the stage to the output in rounds of
+// kDRound. Only wavefronts whose 64 windows are neighbours, light (<= 64 slots) and packed are handled that way;
+// any other slice is counted by the general enumeration and listed for k_fill_slices. A batch that is not
+// position-sorted would list everything, so this kernel is launched next to k_query_fused and a device-side probe of
+// the query order (k_probe_order) decides which of the two does the launch's work; the other returns at once.
+constexpr uint32_t kDRound = 2 * kPStage;  // ids per round: the wavefront's whole stage
+
+__global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_in, PipeArgs a_in) {
+  (void)v_in;
+  (void)a_in;
+  kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+  __shared__ SegDesc s_seg[kLdsSegs];
+  __shared__ uint2 s_cs[kLdsChroms];
+  __shared__ TileSlot s_slot[kRing];
+  __shared__ uint4 s_keep[kWorkers * kWave * (kPKeep / 4)];   // the wavefronts' slabs
+  __shared__ uint32_t s_stage[kWorkers][2 * kPStage];
+  {  // the order probe's verdict: this launch's sequence number if the batch is position-sorted
+    kargs_t p = fresh(ka);
+    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(p->a.ws + kWsOrder), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    if (w != p->a.seq) return;
+  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  {
+    kargs_t p = fresh(ka);
+    const uint4 *src = reinterpret_cast<const uint4 *>(p->v.seg);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_seg);
+    const uint32_t nseg2 = p->v.nseg * 2, nchrom = p->v.nchrom;
+    for (uint32_t t = threadIdx.x; t < nseg2; t += kPThreads) dst[t] = src[t];
+    const uint2 *rng = p->v.chrom_rng;
+    for (uint32_t t = threadIdx.x; t < nchrom; t += kPThreads) s_cs[t] = rng[t];
+    if (threadIdx.x < kRing) {
+      s_slot[threadIdx.x].gen_ticket = 0;
+      s_slot[threadIdx.x].gen_base = 0;
+      s_slot[threadIdx.x].arrived = 0;
+      s_slot[threadIdx.x].flushed = 0;
+    }
+  }
+  __syncthreads();
+  const SegDesc *const segs = s_seg;
+  const uint2 *const cs = s_cs;
+  if (wave == kWorkers) {
+    pipe_service_wave(ka, s_slot, lane);
+    return;
+  }
+
+  auto tid = [] {
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+  };
+  auto slab_of_wave = [&] { return &s_keep[(tid() & ~(uint32_t)(kWave - 1)) * (kPKeep / 4)]; };
+  auto query_of = [&](uint32_t t) {
+    kargs_t p = fresh(ka);
+    const size_t q = p->a.q_begin + (size_t)t * kPTile + threadIdx.x;
+    IndexView w;
+    w.nchrom = p->v.nchrom;
+    w.flt_qaux = nullptr;
+    return load_query<false>(w, cs, p->a.qchrom, p->a.qlow, p->a.qhigh, q, t < p->a.ntiles && q < p->a.q_end);
+  };
+  auto window_of = [&](const Query &q) {  // as in k_query_pipe
+    Win w{0u, 0u, 0u, 0u};
+    if (q.nseg) {
+      const SegDesc d = load_seg(segs + q.s0);
+      const uint32_t x = q.lo > d.maxlen ? q.lo - d.maxlen : 0u;
+      if (!(q.hi < d.base || x > d.last || q.hi < x)) {
+        const uint32_t sh = d.shift & 31u;
+        const uint32_t ca = x <= d.base ? 0u : (x - d.base) >> sh;
+        const uint32_t cb = q.hi >= d.last ? d.ncell : ((q.hi - d.base) >> sh) + 1u;
+        const char *t = reinterpret_cast<const char *>(fresh(ka)->v.table);
+        w.a = *reinterpret_cast<const uint32_t *>(t + ((d.table_off + ca) << 2));
+        w.b = *reinterpret_cast<const uint32_t *>(t + ((d.table_off + cb) << 2));
+        w.base = d.base + (ca << sh);
+        w.fl = 1u | ((d.shift & kSegPacked) != 0 && ((uint64_t)(cb - ca) << sh) <= 65536ull ? 2u : 0u);
+      }
+    }
+    return w;
+  };
+
+  // A pending slice: counted and reported, output deferred by two iterations. Three registers per lane:
+  //   slab slice (its ids come back out of the slab): x = the lane's hit mask; st = first position within the slice
+  //   << 15 | (window's first even slot - lbase) << 7 | hits — a slab slice has at most 64 x 64 ids, 256 slots;
+  //   any other slice: x = first position within the slice (64 bits), st = hits; it is listed for k_fill_slices
+  //   if ids are asked for.
+  struct Pending {
+    bool have, slab;
+    uint32_t tile, wtotal, lbase, npairs;  // wavefront-uniform
+    uint64_t x;
+    uint32_t st;
+  };
+  Pending pa{false, false, 0u, 0u, 0u, 0u, 0ull, 0u}, pb = pa;
+
+  // the first slab row of the slice about to be flushed, fetched ahead (one 16-byte row per lane covers 128 records;
+  // a longer slab fetches its second row when it is needed)
+  uint4 row0 = make_uint4(0u, 0u, 0u, 0u);
+  auto fetch_row0 = [&](const Pending &pd) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(fresh(ka)->v.rec) + (pd.lbase >> 1);
+    const uint32_t l = tid() & (kWave - 1);
+    if (l < pd.npairs) row0 = src[l];
+  };
+
+  auto flush = [&](const Pending &pd, uint32_t j, bool have_row0) {
+    TileSlot &os = s_slot[j % kRing];
+    uint32_t *const stage = s_stage[wave];
+    kargs_t p0 = fresh(ka);
+    const uint64_t cap = p0->a.cap;
+    const bool ids = pd.slab && cap != 0 && pd.wtotal != 0;
+    if (ids) {
+      if (!have_row0) fetch_row0(pd);
+      uint4 *const slab = slab_of_wave();
+      const uint32_t l = tid() & (kWave - 1);
+      if (l + kWave < pd.npairs)
+        slab[l + kWave] = (reinterpret_cast<const uint4 *>(p0->v.rec) + (pd.lbase >> 1))[l + kWave];
+      if (l < pd.npairs) slab[l] = row0;
+    }
+    lds_wait_eq(&os.gen_base, j + 1);
+    const uint64_t wpos0 = os.base + os.wbase[wave];
+    kargs_t p = fresh(ka);
+    const size_t q_end = p->a.q_end;
+    const size_t q = p->a.q_begin + (size_t)pd.tile * kPTile + threadIdx.x;
+    uint64_t *off = p->a.offsets;
+    if (pd.slab) {
+      const uint32_t loff = pd.st >> 15, cnt = pd.st & 127u;
+      if (q < q_end) {
+        off[q] = wpos0 + loff;
+        if (q == q_end - 1) off[q_end] = wpos0 + loff + cnt;
+      }
+      if (ids) {
+        wave_sync_lds();  // the slab is in place
+        uint32_t *hits = p->a.hits;
+        const uint2 *s2 = reinterpret_cast<const uint2 *>(slab_of_wave()) + ((pd.st >> 7) & 255u);
+        uint64_t mrem = pd.x;
+        uint32_t pos = loff;
+        const uint32_t end = loff + cnt;
+        for (uint32_t r0 = 0; r0 < pd.wtotal; r0 += kDRound) {
+          // a lane's ids enter the stage in order, over one or more consecutive rounds
+          const uint32_t stop = end < r0 + kDRound ? end : r0 + kDRound;
+          while (pos < stop) {
+            const uint32_t jj = (uint32_t)__ffsll((long long)mrem) - 1u;
+            mrem &= mrem - 1;
+            stage[pos - r0] = s2[jj].y;
+            ++pos;
+          }
+          wave_sync_lds();
+          const uint32_t n = pd.wtotal - r0 < kDRound ? pd.wtotal - r0 : kDRound;
+          for (uint32_t i = tid() & (kWave - 1); i < n; i += kWave) {
+            const uint64_t o = wpos0 + r0 + i;
+            if (o < cap) hits[o] = stage[i];
+          }
+          wave_sync_lds();
+        }
+      }
+    } else {
+      if (q < q_end) {
+        off[q] = wpos0 + pd.x;
+        if (q == q_end - 1) off[q_end] = wpos0 + pd.x + pd.st;
+      }
+      if (cap != 0 && lane == 0) {
+        uint64_t *ws = p->a.ws;
+        uint32_t *todo = reinterpret_cast<uint32_t *>(ws + kWsStatus + kFMaxGroups + kFMaxTiles);
+        todo[atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTodo), 1u)] = pd.tile * 16u + (uint32_t)wave;
+      }
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&os.flushed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  lds_wait_eq(&s_slot[0].gen_ticket, 1u);
+  uint32_t tile = __builtin_amdgcn_readfirstlane(s_slot[0].tile);
+  uint32_t qlo, qhi;
+  Win wn;
+  {
+    const Query q0 = query_of(tile);
+    qlo = q0.lo;
+    qhi = q0.hi;
+    wn = window_of(q0);
+  }
+
+  for (uint32_t it = 0;; ++it) {
+    const bool live = tile < A(ntiles);
+    bool in_slab_path = false;
+    uint32_t lbase = 0, npairs = 0, al = 0, cnt = 0, loff = 0, wtotal = 0;
+    uint64_t mask = 0, lpos64 = 0;
+    if (live) {
+      const bool nonempty = (wn.fl & 1u) != 0 && wn.b > wn.a;
+      al = wn.a & ~1u;
+      // every window of the wavefront light, packed and inside one slab?
+      lbase = wave_min(nonempty ? al : 0xFFFFFFFFu);
+      const bool fits = !nonempty || ((wn.fl & 2u) != 0 && wn.b - al <= kLight && wn.b - lbase <= kPKeep * (kWave / 2));
+      in_slab_path = !__any(!fits);
+      if (in_slab_path) {
+        if (__any(nonempty)) {
+          npairs = (wave_max(nonempty ? wn.b : 0u) - lbase + 1u) >> 1;  // fits the slab; rec[] carries two spare slots
+        } else {
+          lbase = 0;
+        }
+        const uint4 *src = reinterpret_cast<const uint4 *>(fresh(ka)->v.rec) + (lbase >> 1);
+        uint4 *const slab = slab_of_wave();
+        for (uint32_t i = tid() & (kWave - 1); i < npairs; i += kWave) slab[i] = src[i];
+        wave_sync_lds();
+        const Window w{wn.a, wn.b, wn.base, 1u, true};
+        const bool short32 = !__any(nonempty && wn.b - al >= 32u);
+        mask = short32 ? (uint64_t)slab_mask32(slab, lbase, w, qlo, qhi, nonempty)
+                       : slab_mask64(slab, lbase, w, qlo, qhi, nonempty);
+        cnt = (uint32_t)__popcll(mask);
+      } else {
+        kargs_t p = fresh(ka);
+        IndexView v1;
+        v1.se = p->v.se;
+        v1.rec = p->v.rec;
+        v1.id = p->v.id;
+        v1.table = p->v.table;
+        v1.seg = nullptr;
+        v1.chrom_rng = nullptr;
+        v1.nchrom = 0;
+        v1.nseg = 0;
+        v1.max_segs = 1;
+        v1.nslots = 0;
+        v1.flt_kind = BIVX_FILTER_NONE;
+        v1.flt_dist = 0;
+        v1.flt_strand = 0;
+        v1.flt_qaux = nullptr;
+        v1.flt_iaux = nullptr;
+        v1.err = nullptr;
+        const Query qy = query_of(tile);
+        cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, false>(v1, segs, qy, nullptr, 0, 0, nullptr);
+      }
+      const uint32_t incl = wave_scan_incl(cnt);
+      loff = incl - cnt;
+      const bool huge = __any(cnt >= (1u << 22));
+      wtotal = wave_last(incl);
+      uint64_t wt64 = wtotal;
+      lpos64 = loff;
+      if (huge) {
+        uint64_t i64 = cnt;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+          const uint64_t o = __shfl_up((unsigned long long)i64, d, kWave);
+          if (lane >= d) i64 += o;
+        }
+        lpos64 = i64 - cnt;
+        wt64 = __shfl((unsigned long long)i64, kWave - 1, kWave);
+      }
+      TileSlot &sl = s_slot[it % kRing];
+      if (lane == 0) {
+        sl.wsum[wave] = wt64;
+        __hip_atomic_fetch_add(&sl.arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    // the slab of the slice that goes out in this iteration is on its way while the ticket is waited for
+    const bool want_row = pb.have && pb.slab && pb.wtotal != 0 && A(cap) != 0;
+    if (want_row) fetch_row0(pb);
+
+    uint32_t ntile = 0xFFFFFFFFu;
+    Query nqy{0u, 0u, 0u, 0u, 0u};
+    if (live) {
+      TileSlot &nx = s_slot[(it + 1) % kRing];
+      lds_wait_eq(&nx.gen_ticket, it + 2);
+      ntile = __builtin_amdgcn_readfirstlane(nx.tile);
+      nqy = query_of(ntile);
+    }
+    if (pb.have) flush(pb, it - 2, want_row);
+    if (!live) {
+      if (pa.have) flush(pa, it - 1, false);
+      break;
+    }
+    const Win nwn = window_of(nqy);
+    pb = pa;
+    pa = Pending{true, in_slab_path, tile, wtotal, lbase, npairs, in_slab_path ? mask : lpos64,
+                 in_slab_path ? (loff << 15) | ((al - lbase) & 255u) << 7 | cnt : cnt};
+    tile = ntile;
+    qlo = nqy.lo;
+    qhi = nqy.hi;
+    wn = nwn;
+  }
+}
+
+// Is the batch in position order? 4096 neighbouring pairs, evenly spread: (chromosome, low) must not descend in more
+// than 2 % of them. Leaves the launch's sequence number in ws[kWsOrder] if so, 0 otherwise.
+__global__ __launch_bounds__(256) void k_probe_order(const uint32_t *__restrict__ qchrom, const uint32_t *__restrict__ qlow,
+                                                      size_t q0, size_t q1, uint64_t *ws, uint32_t seq) {
+  __shared__ uint32_t s_desc[4];
+  const size_t n = q1 - q0;
+  uint32_t desc = 0;
+  for (uint32_t k = 0; k < 16; ++k) {
+    const size_t i = q0 + (size_t)((unsigned __int128)(n - 1) * (threadIdx.x * 16u + k) / 4096u);
+    if (i + 1 < q1) {
+      const uint32_t c0 = qchrom ? qchrom[i] : 0u, c1 = qchrom ? qchrom[i + 1] : 0u;
+      desc += (c0 > c1 || (c0 == c1 && qlow[i] > qlow[i + 1])) ? 1u : 0u;
+    }
+  }
+  desc = wave_sum(desc);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_desc[threadIdx.x >> 6] = desc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t d = s_desc[0] + s_desc[1] + s_desc[2] + s_desc[3];
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + kWsOrder), d * 50u <= 4096u ? seq : 0u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+#undef A
 
 // Fills the ids of the slices k_query_pipe listed: offsets are in place, the enumeration is the general one
 // (k_query<Fill>'s, wavefront-cooperative windows included). One work item = one slice (64 queries, one wavefront);
@@ -707,6 +1021,18 @@ bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bo
   return cap <= (uint64_t)6 * q;
 }
 
+// Many ids per query (more than the stages hold): the regenerating form of the pipeline, for position-sorted batches
+// (the kernel itself returns at once when k_probe_order found the batch unsorted; the caller launches k_query_fused
+// behind it with the opposite condition).
+bool pipe_dense_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bool unordered) {
+  const char *env = std::getenv("BIVX_PIPE");
+  const int mode = env ? std::atoi(env) : 1;
+  if (!mode || unordered || sort_ids || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
+  if (v.nslots > (1u << 28)) return false;
+  if (q < (size_t)4 * 512 * kPTile && mode != 2) return false;
+  return cap > (uint64_t)6 * q;
+}
+
 size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }
 
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
@@ -733,6 +1059,30 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
     hipLaunchKernelGGL(k_fill_slices<true>, dim3(256), dim3(kQThreads), 0, s, v, a);
   else
     hipLaunchKernelGGL(k_fill_slices<false>, dim3(256), dim3(kQThreads), 0, s, v, a);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                            size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
+                            int flags, uint32_t seq, hipStream_t s) {
+  const unsigned tiles = (unsigned)((q1 - q0 + kPTile - 1) / kPTile);
+  unsigned wgs = 512;
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      wgs = 2u * (unsigned)cus;
+    if (const char *e = std::getenv("BIVX_PIPE_WGS")) {
+      const long w = std::atol(e);
+      if (w >= 1 && w <= 65536) wgs = (unsigned)w;
+    }
+  }
+  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, seq};
+  hipLaunchKernelGGL(k_probe_order, dim3(1), dim3(256), 0, s, d_qchrom, d_qlow, q0, q1, ws, seq);
+  hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
+  a.seq = 0;  // (k_fill_slices: index order)
+  hipLaunchKernelGGL(k_fill_slices<false>, dim3(256), dim3(kQThreads), 0, s, v, a);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

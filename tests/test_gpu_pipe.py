@@ -154,6 +154,48 @@ def test_ascending_ids_for_lists_of_every_staged_length():
     assert np.array_equal(hits_s[:H], hits_u[:H][order])
 
 
+@pytest.mark.parametrize("order", ["sorted", "nearly", "generated"])
+def test_many_ids_per_query_position_sorted_batches(oracle, order):
+    """Config-5 density (an index overlapped with itself, ~17 ids per query): the regenerating form of the pipeline
+    (k_query_pipe_dense) does position-sorted batches, k_query_fused everything else — a device-side probe of the
+    query order decides, so the same call must give the same CSR whatever the order and whichever kernel ran."""
+    import torch
+    from binary_amd import IntervalIndex, synth
+    n = 600_000
+    low, high = synth.gen_intervals(n, 37_000_000, 1000, 5)
+    # a few chromosome-wide intervals' worth of long windows and a pile of 200 intervals over one point: slices that
+    # cannot come out of a slab are listed and filled behind the kernel
+    rng = np.random.default_rng(2)
+    pile = np.full(200, 20_000_000, dtype=np.uint32)
+    low = np.concatenate([low, pile - rng.integers(1, 500, 200).astype(np.uint32)])
+    high = np.concatenate([high, pile + rng.integers(1, 500, 200).astype(np.uint32)])
+    qlo, qhi = low.copy(), high.copy()
+    if order != "generated":
+        p = np.argsort(qlo, kind="stable")
+        if order == "nearly":
+            sw = rng.permutation(p.size)[: p.size // 100]
+            p[sw] = p[np.roll(sw, 1)]
+        qlo, qhi = qlo[p], qhi[p]
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        H, ((off_p, hits_p), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi))
+        assert H > 10 * qlo.size
+        assert np.array_equal(off_p, off_f) and np.array_equal(hits_p[:H], hits_f[:H])
+        cap = H // 2
+        H2, ((off_c, hits_c), _) = _both(idx, to(qlo), to(qhi), cap=cap, workspace=True)
+        assert np.array_equal(off_c, off_f) and np.array_equal(hits_c[:cap], hits_f[:cap])
+        assert idx.stats()["prefix_timeouts"] == 0
+    assert np.array_equal(np.diff(off_p), oracle.count_overlaps_numpy(low, high, qlo, qhi))
+    t = oracle.OracleTree(low, high)
+    sel = np.arange(0, qlo.size, 997)
+    off_o, hits_o = t.find_overlaps_batch(qlo[sel], qhi[sel])
+    got = np.concatenate([np.sort(hits_p[off_p[i]:off_p[i + 1]]) for i in sel]).astype(np.int64)
+    assert np.array_equal(got, oracle.sorted_csr(off_o, hits_o))
+
+
 def test_chained_launches_and_few_workgroups():
     import torch
     from binary_amd import IntervalIndex, synth
