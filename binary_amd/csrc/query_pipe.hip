@@ -433,11 +433,12 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       }
       const uint64_t cap = p->a.cap;
       if (cap != 0) {
-        uint32_t *hits = p->a.hits;
-        for (uint32_t i = tid() & (kWave - 1); i < pd.wtotal; i += kWave) {
-          const uint64_t pos = wpos0 + i;
-          if (pos < cap) hits[pos] = stage[i];
-        }
+        // (the slice's first output position is the same in every lane: a scalar base, 32-bit lane offsets)
+        const uint64_t wp = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)wpos0) |
+                            (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wpos0 >> 32)) << 32;
+        uint32_t *const out = p->a.hits + wp;
+        const uint32_t lim = cap > wp ? (cap - wp < pd.wtotal ? (uint32_t)(cap - wp) : pd.wtotal) : 0u;
+        for (uint32_t i = tid() & (kWave - 1); i < lim; i += kWave) out[i] = stage[i];
       }
     } else {
       // an unstaged slice kept (list offset, count) per lane in its stage; its ids are k_fill_slices' business
@@ -781,26 +782,41 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
       }
       if (ids) {
         wave_sync_lds();  // the slab is in place
-        uint32_t *hits = p->a.hits;
+        // (the slice's first output position is the same in every lane: a scalar base, 32-bit lane offsets)
+        const uint64_t wp = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)wpos0) |
+                            (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wpos0 >> 32)) << 32;
+        uint32_t *const out = p->a.hits + wp;
+        const uint32_t room = cap > wp ? (cap - wp < 0xFFFFFFFFull ? (uint32_t)(cap - wp) : 0xFFFFFFFFu) : 0u;
         const uint2 *s2 = reinterpret_cast<const uint2 *>(slab_of_wave()) + ((pd.st >> 7) & 255u);
-        uint64_t mrem = pd.x;
+        // the mask is walked one 32-bit word at a time (find-first-set and clear-lowest are one and two instructions
+        // on a word, four each on 64 bits)
+        uint32_t mw = (uint32_t)pd.x, mhi = (uint32_t)(pd.x >> 32), jbase = 0;
+        if (mw == 0u) {
+          mw = mhi;
+          mhi = 0u;
+          jbase = 32u;
+        }
         uint32_t pos = loff;
         const uint32_t end = loff + cnt;
         for (uint32_t r0 = 0; r0 < pd.wtotal; r0 += kDRound) {
           // a lane's ids enter the stage in order, over one or more consecutive rounds
           const uint32_t stop = end < r0 + kDRound ? end : r0 + kDRound;
+          uint32_t *dst = stage + (pos - r0);
           while (pos < stop) {
-            const uint32_t jj = (uint32_t)__ffsll((long long)mrem) - 1u;
-            mrem &= mrem - 1;
-            stage[pos - r0] = s2[jj].y;
+            const uint32_t jj = (uint32_t)__ffs((int)mw) - 1u;
+            mw &= mw - 1u;
+            *dst++ = s2[jbase + jj].y;
             ++pos;
+            if (mw == 0u) {
+              mw = mhi;
+              mhi = 0u;
+              jbase = 32u;
+            }
           }
           wave_sync_lds();
           const uint32_t n = pd.wtotal - r0 < kDRound ? pd.wtotal - r0 : kDRound;
-          for (uint32_t i = tid() & (kWave - 1); i < n; i += kWave) {
-            const uint64_t o = wpos0 + r0 + i;
-            if (o < cap) hits[o] = stage[i];
-          }
+          const uint32_t lim = room > r0 ? (room - r0 < n ? room - r0 : n) : 0u;
+          for (uint32_t i = tid() & (kWave - 1); i < lim; i += kWave) out[r0 + i] = stage[i];
           wave_sync_lds();
         }
       }
