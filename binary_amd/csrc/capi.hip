@@ -958,7 +958,9 @@ const char *bivx_query_kernel_name(const bivx_index *idx, size_t q, uint64_t hit
   if (!idx || idx->sharded || !idx->built) return "";
   IndexView view;
   if (view_with_filter(idx, filter, view) != 0) return "";
-  return pipe_eligible(view, q, hit_capacity, sort_by_id != 0, false) ? "k_query_pipe" : "k_query_fused";
+  if (pipe_eligible(view, q, hit_capacity, sort_by_id != 0, false)) return "k_query_pipe";
+  if (pipe_dense_eligible(view, q, hit_capacity, sort_by_id != 0, false)) return "k_query_pipe_dense|k_query_fused";
+  return "k_query_fused";
 }
 
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q, void *stream) {

@@ -13,15 +13,27 @@ from collections import defaultdict
 
 acc = defaultdict(list)
 KERNEL = "k_query_fused"
+if len(sys.argv) > 3:  # the bench line names the kernel that did the work
+    try:
+        KERNEL = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])["roofline"]["dominant_kernel"]
+    except Exception:
+        pass
+
+
+def is_it(name):
+    # "k_query_pipe" must not match k_query_pipe_dense
+    return (KERNEL + "<") in name or (KERNEL + "(") in name or name.rstrip().endswith(KERNEL) or \
+        (KERNEL == "k_query_pipe_dense" and KERNEL in name)
+
+
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "k_query_fused" in r["Kernel_Name"] or "k_query_pipe" in r["Kernel_Name"]]
-    if any("k_query_pipe" in r["Kernel_Name"] for r in rows):  # the steps run the pipelined kernel (the sizing count too)
-        rows = [r for r in rows if "k_query_pipe" in r["Kernel_Name"]]
-        KERNEL = "k_query_pipe"
-    # the first launch of the kernel in a bench run is the zero-capacity count that sizes the hit buffer, not a step
+    rows = [r for r in csv.DictReader(open(f)) if is_it(r["Kernel_Name"])]
+    # the first launch of the kernel in a bench run may be the zero-capacity count that sizes the hit buffer, not a
+    # step (when that count runs on the same kernel)
     first = min((int(r["Dispatch_Id"]) for r in rows), default=None)
+    skip_first = KERNEL != "k_query_pipe_dense"
     for r in rows:
-        if int(r["Dispatch_Id"]) != first:
+        if not (skip_first and int(r["Dispatch_Id"]) == first):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
 rd = avg.get("TCC_EA0_RDREQ_sum", 0.0)
