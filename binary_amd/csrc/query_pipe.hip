@@ -1030,9 +1030,9 @@ bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bo
   const int mode = env ? std::atoi(env) : 1;
   if (!mode || unordered || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
   if (v.nslots > (1u << 28)) return false;  // (32-bit byte offsets into the records, lanes_mask32)
-  // batches of a few tiles per resident workgroup gain nothing from a pipeline that has to fill and drain
-  // (config 2, 977 tiles: 60 us against 55 for k_query_fused)
-  if (q < (size_t)4 * 512 * kPTile && mode != 2) return false;
+  // a pipeline has to fill and drain: below about 0.7 M queries (1.4 tiles per resident workgroup) k_query_fused is
+  // the faster one (0.25 M: 19.7 against 23.7 us, 0.5 M: 32 / 35, 0.75 M: 45 / 43, 1 M: 54 / 49, 1.3 M: 70 / 60)
+  if (q < (size_t)768 * 1024 && mode != 2) return false;
   // few ids per query: a wavefront's 64 lists must fit its stage (the capacity is the only bound the host has)
   return cap <= (uint64_t)6 * q;
 }

@@ -172,9 +172,9 @@ int bivx_query_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32
  * that every status is surfaced). */
 int bivx_stream_status(const bivx_index *idx, void *stream);
 
-/* Which kernel bivx_query_dev* runs for such a call: "k_query_pipe" (the pipelined form, for batches of about 2 M
+/* Which kernel bivx_query_dev* runs for such a call: "k_query_pipe" (the pipelined form, for batches of about 0.8 M
  * queries and more on an index with one length class per chromosome, no post-filter, at most 6 ids per query of
- * capacity), "k_query_pipe_dense|k_query_fused" (the same conditions with more ids per query and index order: both are
+ * capacity), "k_query_pipe_dense|k_query_fused" (2 M queries and more, more ids per query, index order: both are
  * launched, a device-side probe of the query order picks the first for a position-sorted batch, the second otherwise,
  * and the other returns at once) or "k_query_fused" (everything else). Same results whichever runs; the names are what
  * shows up in a rocprofv3 kernel trace (bench.py reports the one that did the work as the dominant kernel). */

@@ -1,6 +1,6 @@
 """The pipelined single-pass kernel (binary_amd/csrc/query_pipe.hip: persistent workgroups, worker and service
 wavefronts, output deferred by two iterations) against k_query_fused and the oracle. By default it only takes batches of
-2 M queries and more; BIVX_PIPE=2 sends every eligible batch through it, BIVX_PIPE=0 none, so the two kernels can be
+0.8 M queries and more; BIVX_PIPE=2 sends every eligible batch through it, BIVX_PIPE=0 none, so the two kernels can be
 compared bit for bit on the same inputs: offsets AND ids in index order must be identical."""
 import os
 
