@@ -20,6 +20,9 @@ constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsNeedSort = 24, 
 // ws[kWsOrder]: sequence number of the last launch whose batch k_probe_order found position-sorted (query_pipe.hip)
 // ws[kWsNeedSort]: sequence number of the last launch that left lists for k_sort_hits to order (never cleared:
 // every launch carries a fresh number)
+// the pipelined kernels' list of slices behind the status array (u64 index; u32 entries, 16 per tile: a tile has 15
+// slices and in the worst case every one of them is listed)
+constexpr uint32_t kWsList = kWsStatus + kFMaxGroups + kFMaxTiles, kWsListWords = kFMaxTiles * 8;
 constexpr uint32_t kDoneShift = 44;  // unordered output: ws[kWsDone] = departures << 44 | ids reserved by this launch
 // k_query_fused flags: index-owned workspace; last launch of the call; bits 8-15: log2 of the bound on a prefix
 // wait in ticks of the 100 MHz constant clock (0 = kWaitLog2Default)

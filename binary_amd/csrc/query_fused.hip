@@ -436,8 +436,8 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
 
 size_t fused_workspace_bytes(size_t q) {
   (void)q;
-  // header words, group words, tile words, then the pipelined kernel's list of tiles left for k_fill_tiles (u32 each)
-  return ((size_t)kFMaxTiles + kFMaxGroups + kWsStatus) * sizeof(uint64_t) + (size_t)kFMaxTiles * sizeof(uint32_t);
+  // header words, group words, tile words, then the pipelined kernels' list of slices left for k_fill_slices
+  return ((size_t)kWsList + kWsListWords) * sizeof(uint64_t);
 }
 
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,

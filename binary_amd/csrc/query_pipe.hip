@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       }
       if (lane == 0) {
         uint64_t *ws = p->a.ws;
-        uint32_t *todo = reinterpret_cast<uint32_t *>(ws + kWsStatus + kFMaxGroups + kFMaxTiles);
+        uint32_t *todo = reinterpret_cast<uint32_t *>(ws + kWsList);
         todo[atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTodo), 1u)] = pd.tile * 16u + (uint32_t)wave;
       }
     }
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
       }
       if (cap != 0 && lane == 0) {
         uint64_t *ws = p->a.ws;
-        uint32_t *todo = reinterpret_cast<uint32_t *>(ws + kWsStatus + kFMaxGroups + kFMaxTiles);
+        uint32_t *todo = reinterpret_cast<uint32_t *>(ws + kWsList);
         todo[atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTodo), 1u)] = pd.tile * 16u + (uint32_t)wave;
       }
     }
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ uint32_t s_last;
   __shared__ uint32_t s_sort[S ? kQWaves : 1][S ? kSortLds / 2 : 1];
-  const uint32_t *todo = reinterpret_cast<const uint32_t *>(a.ws + kWsStatus + kFMaxGroups + kFMaxTiles);
+  const uint32_t *todo = reinterpret_cast<const uint32_t *>(a.ws + kWsList);
   const uint32_t n =
       __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.ws + kWsTodo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (n == 0) return;  // (nothing was listed: nobody touched the counters either)

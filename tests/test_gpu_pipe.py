@@ -196,6 +196,42 @@ def test_many_ids_per_query_position_sorted_batches(oracle, order):
     assert np.array_equal(got, oracle.sorted_csr(off_o, hits_o))
 
 
+def test_every_slice_of_a_large_batch_listed():
+    """4 584 tiles whose slices all overflow their stage (5.6 ids per query: ~360 per wavefront against 320) while the
+    capacity still says "at most 6 per query": 68 760 listed slices — the list must hold 15 entries per tile, not one
+    (it was sized per tile at first)."""
+    import torch
+    from binary_amd import IntervalIndex, synth
+    low, high = synth.gen_intervals(1_000_000, 89_000_000, 1000, 3)
+    qlo, qhi = synth.gen_point_queries(4_400_000, 89_000_000, 4)
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        d_qlo, d_qhi = to(qlo), to(qhi)
+        off = idx.count_overlaps_device(d_qlo, d_qhi)
+        H = int(off[-1].item())
+        assert 5.2 * qlo.size < H <= 6 * qlo.size
+        assert idx.query_kernel_name(qlo.size, H) == "k_query_pipe"
+        res = []
+        for mode in (1, 0):
+            with _env(BIVX_PIPE=mode):
+                o = torch.empty(qlo.size + 1, dtype=torch.int64, device=dev)
+                h = torch.full((H,), -1, dtype=torch.int32, device=dev)
+                idx.query_device(d_qlo, d_qhi, o, h)
+                idx.stream_status()
+                res.append((o, h))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert torch.equal(res[0][0], off)
+        # and the next call on the same workspace is clean
+        o = torch.empty(qlo.size + 1, dtype=torch.int64, device=dev)
+        h = torch.full((H,), -1, dtype=torch.int32, device=dev)
+        idx.query_device(d_qlo, d_qhi, o, h)
+        idx.stream_status()
+        assert torch.equal(o, off) and torch.equal(h, res[1][1])
+
+
 def test_chained_launches_and_few_workgroups():
     import torch
     from binary_amd import IntervalIndex, synth
