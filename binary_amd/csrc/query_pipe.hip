@@ -40,6 +40,10 @@ constexpr int kWorkers = kPWaves - 1;          // wavefront kWorkers is the serv
 constexpr uint32_t kPTile = kWorkers * kWave;  // 960 queries
 constexpr uint32_t kRing = 8;                  // tile slots in LDS
 constexpr uint32_t kPStage = 320;   // ids per wavefront stage (there are two: a slice waits two iterations for its base)
+#ifndef BIVX_FILL_BLOCKS
+#define BIVX_FILL_BLOCKS 256
+#endif
+constexpr unsigned kFillBlocks = BIVX_FILL_BLOCKS;  // workgroups (of four wavefronts) of k_fill_slices
 constexpr uint32_t kPKeep = 8;      // ids kept per query while counting (a wavefront's 64 x 8 slots are its slab too)
 
 // Diagnostic build only (-DBIVX_STAMPS): wall-clock stamps of worker 0, written to a buffer no other code reads.
@@ -613,24 +617,32 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       }
     }
     if (S && staged && !no_ids) {
-      // Every lane orders its own list where it lies (ids are distinct inside a query): up to eight ids are ranked in
-      // registers; a longer list is ranked into the keep slots, which are idle until the next tile is counted, and
-      // copied back. Lane-local throughout — a wavefront's LDS operations execute in order, nothing to wait for.
+      // Every lane orders its own list where it lies (ids are distinct inside a query): up to eight ids go through a
+      // sorting network in registers; a longer list is ranked into the keep slots, which are idle until the next tile
+      // is counted, and copied back. Lane-local throughout — a wavefront's LDS operations execute in order, nothing to wait for.
       wave_sync_lds();  // (the slab next door may still be read by this wavefront's other lanes)
       if (cnt > 1 && cnt <= 8u) {
-        uint32_t x[8], rank[8];
+        // a 19-comparator network on eight registers (missing ids are +inf and stay behind the list's end)
+        uint32_t x[8];
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k) x[k] = k < cnt ? stage[loff + k] : 0xFFFFFFFFu;
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) {
-          rank[k] = 0;
-#pragma unroll
-          for (uint32_t j = 0; j < 8u; ++j)
-            if (j != k) rank[k] += x[j] < x[k] ? 1u : 0u;
-        }
+#define BIVX_CE(i, j)                      \
+  {                                        \
+    const uint32_t lo_ = min(x[i], x[j]);  \
+    x[j] = max(x[i], x[j]);                \
+    x[i] = lo_;                            \
+  }
+        BIVX_CE(0, 1) BIVX_CE(2, 3) BIVX_CE(4, 5) BIVX_CE(6, 7)
+        BIVX_CE(0, 2) BIVX_CE(1, 3) BIVX_CE(4, 6) BIVX_CE(5, 7)
+        BIVX_CE(1, 2) BIVX_CE(5, 6) BIVX_CE(0, 4) BIVX_CE(3, 7)
+        BIVX_CE(1, 5) BIVX_CE(2, 6)
+        BIVX_CE(1, 4) BIVX_CE(3, 6)
+        BIVX_CE(2, 4) BIVX_CE(3, 5)
+        BIVX_CE(3, 4)
+#undef BIVX_CE
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k)
-          if (k < cnt) stage[loff + rank[k]] = x[k];
+          if (k < cnt) stage[loff + k] = x[k];
       } else if (cnt > 8u) {
         uint32_t *const tmp = reinterpret_cast<uint32_t *>(slab_of_wave());
         rank_sort_list<8>(stage, tmp, loff, cnt);
@@ -1072,9 +1084,9 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
   else
     hipLaunchKernelGGL(k_query_pipe<false>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   if (sort_seq)
-    hipLaunchKernelGGL(k_fill_slices<true>, dim3(256), dim3(kQThreads), 0, s, v, a);
+    hipLaunchKernelGGL(k_fill_slices<true>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
   else
-    hipLaunchKernelGGL(k_fill_slices<false>, dim3(256), dim3(kQThreads), 0, s, v, a);
+    hipLaunchKernelGGL(k_fill_slices<false>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -1098,7 +1110,7 @@ int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const 
   hipLaunchKernelGGL(k_probe_order, dim3(1), dim3(256), 0, s, d_qchrom, d_qlow, q0, q1, ws, seq);
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   a.seq = 0;  // (k_fill_slices: index order)
-  hipLaunchKernelGGL(k_fill_slices<false>, dim3(256), dim3(kQThreads), 0, s, v, a);
+  hipLaunchKernelGGL(k_fill_slices<false>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
