@@ -621,29 +621,45 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       // sorting network in registers; a longer list is ranked into the keep slots, which are idle until the next tile
       // is counted, and copied back. Lane-local throughout — a wavefront's LDS operations execute in order, nothing to wait for.
       wave_sync_lds();  // (the slab next door may still be read by this wavefront's other lanes)
-      if (cnt > 1 && cnt <= 8u) {
-        // a 19-comparator network on eight registers (missing ids are +inf and stay behind the list's end)
-        uint32_t x[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) x[k] = k < cnt ? stage[loff + k] : 0xFFFFFFFFu;
 #define BIVX_CE(i, j)                      \
   {                                        \
     const uint32_t lo_ = min(x[i], x[j]);  \
     x[j] = max(x[i], x[j]);                \
     x[i] = lo_;                            \
   }
-        BIVX_CE(0, 1) BIVX_CE(2, 3) BIVX_CE(4, 5) BIVX_CE(6, 7)
-        BIVX_CE(0, 2) BIVX_CE(1, 3) BIVX_CE(4, 6) BIVX_CE(5, 7)
-        BIVX_CE(1, 2) BIVX_CE(5, 6) BIVX_CE(0, 4) BIVX_CE(3, 7)
-        BIVX_CE(1, 5) BIVX_CE(2, 6)
-        BIVX_CE(1, 4) BIVX_CE(3, 6)
-        BIVX_CE(2, 4) BIVX_CE(3, 5)
-        BIVX_CE(3, 4)
-#undef BIVX_CE
+#define BIVX_SORT8(a0, a1, a2, a3, a4, a5, a6, a7) /* 19 comparators; ascending in the order the indexes are given */ \
+  BIVX_CE(a0, a1) BIVX_CE(a2, a3) BIVX_CE(a4, a5) BIVX_CE(a6, a7)                                                   \
+  BIVX_CE(a0, a2) BIVX_CE(a1, a3) BIVX_CE(a4, a6) BIVX_CE(a5, a7)                                                   \
+  BIVX_CE(a1, a2) BIVX_CE(a5, a6) BIVX_CE(a0, a4) BIVX_CE(a3, a7)                                                   \
+  BIVX_CE(a1, a5) BIVX_CE(a2, a6) BIVX_CE(a1, a4) BIVX_CE(a3, a6) BIVX_CE(a2, a4) BIVX_CE(a3, a5) BIVX_CE(a3, a4)
+      if (cnt > 1 && cnt <= 8u) {
+        // a sorting network on eight registers (missing ids are +inf and stay behind the list's end)
+        uint32_t x[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) x[k] = k < cnt ? stage[loff + k] : 0xFFFFFFFFu;
+        BIVX_SORT8(0, 1, 2, 3, 4, 5, 6, 7)
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k)
           if (k < cnt) stage[loff + k] = x[k];
-      } else if (cnt > 8u) {
+      } else if (cnt > 8u && cnt <= 16u) {
+        // sixteen: the first eight ascending, the last eight descending, then a bitonic merge (70 comparators; ranking
+        // a list of ten in LDS costs five times the instructions)
+        uint32_t x[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) x[k] = k < cnt ? stage[loff + k] : 0xFFFFFFFFu;
+        BIVX_SORT8(0, 1, 2, 3, 4, 5, 6, 7)
+        BIVX_SORT8(15, 14, 13, 12, 11, 10, 9, 8)
+#pragma unroll
+        for (uint32_t d = 8; d > 0; d >>= 1)
+#pragma unroll
+          for (uint32_t i = 0; i < 16u; ++i)
+            if ((i & d) == 0) BIVX_CE(i, i + d)
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k)
+          if (k < cnt) stage[loff + k] = x[k];
+#undef BIVX_SORT8
+#undef BIVX_CE
+      } else if (cnt > 16u) {
         uint32_t *const tmp = reinterpret_cast<uint32_t *>(slab_of_wave());
         rank_sort_list<8>(stage, tmp, loff, cnt);
         for (uint32_t k = 0; k < cnt; ++k) stage[loff + k] = tmp[loff + k];
