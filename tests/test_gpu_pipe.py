@@ -196,6 +196,64 @@ def test_many_ids_per_query_position_sorted_batches(oracle, order):
     assert np.array_equal(got, oracle.sorted_csr(off_o, hits_o))
 
 
+@pytest.mark.parametrize("by_id", [False, True])
+def test_edge_coordinates_through_the_pipelined_kernel(oracle, by_id):
+    """The corners test_gpu_parity.py walks through the host entry points, sent through k_query_pipe: coordinates at both
+    ends of uint32, low > high intervals and queries (TraMapper's BND records), touching ends, queries on a chromosome
+    the index does not have, an empty chromosome in the middle."""
+    import torch
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(9)
+    M = 0xFFFFFFFF
+    n = 40_000
+    chrom = rng.integers(0, 5, n).astype(np.uint32)
+    chrom[chrom == 2] = 3                                           # chromosome 2 stays empty
+    low = rng.integers(0, 3_000_000, n).astype(np.uint32)
+    high = (low + rng.integers(0, 900, n)).astype(np.uint32)
+    top = rng.permutation(n)[:4000]                                 # a cluster at the very top of the range
+    low[top] = (M - rng.integers(0, 500_000, 4000)).astype(np.uint32)
+    high[top] = np.minimum(low[top].astype(np.int64) + rng.integers(0, 900, 4000), M).astype(np.uint32)
+    inv = rng.permutation(n)[:3000]                                 # inverted records
+    low[inv], high[inv] = high[inv].copy(), low[inv].copy()
+    low[:4] = [0, 0, M, M - 1]
+    high[:4] = [0, M, M, M]
+    chrom[:4] = 0
+    q = 30_000
+    qc = rng.integers(0, 7, q).astype(np.uint32)                    # 5 and 6 do not exist in the index
+    qlo = rng.integers(0, 3_000_000, q).astype(np.uint32)
+    qhi = (qlo + rng.integers(0, 900, q)).astype(np.uint32)
+    t = rng.permutation(q)[:5000]
+    qlo[t] = (M - rng.integers(0, 500_000, 5000)).astype(np.uint32)
+    qhi[t] = np.minimum(qlo[t].astype(np.int64) + rng.integers(0, 900, 5000), M).astype(np.uint32)
+    qi = rng.permutation(q)[:1500]
+    qlo[qi], qhi[qi] = qhi[qi].copy(), qlo[qi].copy()
+    qlo[:6] = [0, M, 0, 6, 1, M - 500]
+    qhi[:6] = [0, M, M, M - 2, 4, M - 400]
+    qc[:6] = 0
+    touch = rng.permutation(n)[:2000]                               # queries that end exactly where an interval begins
+    qhi[6:2006] = low[touch]
+    qlo[6:2006] = np.minimum(qhi[6:2006], qlo[6:2006])
+    qc[6:2006] = chrom[touch]
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high, chrom)
+        idx.build()
+        H, ((off_p, hits_p), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi), to(qc), sort_by_id=by_id)
+    assert np.array_equal(off_p, off_f) and np.array_equal(hits_p[:H], hits_f[:H])
+    # the predicate itself (interval_tree.hpp:119-121), per chromosome, inverted records and queries included
+    want = np.zeros(q, dtype=np.int64)
+    for c in range(5):
+        mi, mq = np.nonzero(chrom == c)[0], np.nonzero(qc == c)[0]
+        for k in range(0, mq.size, 500):
+            sel = mq[k:k + 500]
+            want[sel] = ((low[mi][None, :] <= qhi[sel][:, None]) & (high[mi][None, :] >= qlo[sel][:, None])).sum(axis=1)
+    assert np.array_equal(np.diff(off_p), want)
+    for i in list(range(8)) + list(rng.integers(0, q, 300)):
+        m = (chrom == qc[i]) & (low <= qhi[i]) & (high >= qlo[i])
+        assert np.array_equal(np.sort(hits_p[off_p[i]:off_p[i + 1]]), np.nonzero(m)[0])
+
+
 def test_every_slice_of_a_large_batch_listed():
     """4 584 tiles whose slices all overflow their stage (5.6 ids per query: ~360 per wavefront against 320) while the
     capacity still says "at most 6 per query": 68 760 listed slices — the list must hold 15 entries per tile, not one
