@@ -39,7 +39,12 @@ constexpr int kPWaves = kPThreads / kWave;
 constexpr int kWorkers = kPWaves - 1;          // wavefront kWorkers is the service wavefront
 constexpr uint32_t kPTile = kWorkers * kWave;  // 960 queries
 constexpr uint32_t kRing = 8;                  // tile slots in LDS
-constexpr uint32_t kPStage = 320;   // ids per wavefront stage (there are two: a slice waits two iterations for its base)
+#ifndef BIVX_DEFER
+#define BIVX_DEFER 2
+#endif
+constexpr uint32_t kDefer = BIVX_DEFER;  // iterations between counting a slice and writing it out (experiments: 1, 3)
+static_assert(kDefer >= 1 && kDefer <= 3, "deferral depth");
+constexpr uint32_t kPStage = kDefer == 2 ? 320 : 640 / kDefer;   // ids per wavefront stage (there are two: a slice waits two iterations for its base)
 #ifndef BIVX_FILL_BLOCKS
 #define BIVX_FILL_BLOCKS 256
 #endif
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ TileSlot s_slot[kRing];
   __shared__ uint4 s_keep[kWorkers * kWave * (kPKeep / 4)];   // keep slots / slabs of the slice being counted
-  __shared__ uint32_t s_stage[kWorkers][2][kPStage];          // ids of the two pending slices, laid out as in the output
+  __shared__ uint32_t s_stage[kWorkers][kDefer][kPStage];     // ids of the pending slices, laid out as in the output
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
@@ -419,11 +424,13 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     bool have, staged;
     uint32_t tile, wtotal, state;
   };
-  Pending pa{false, false, 0u, 0u, 0u}, pb{false, false, 0u, 0u, 0u};
+  Pending pd_[kDefer];
+#pragma unroll
+  for (uint32_t k = 0; k < kDefer; ++k) pd_[k] = Pending{false, false, 0u, 0u, 0u};
   // writes the offsets of a pending slice and streams its ids; `j` is the iteration it was counted in
   auto flush = [&](const Pending &pd, uint32_t j) {
     TileSlot &os = s_slot[j % kRing];
-    uint32_t *const stage = s_stage[wave][j & 1u];
+    uint32_t *const stage = s_stage[wave][j % kDefer];
     lds_wait_eq(&os.gen_base, j + 1);
     const uint64_t wpos0 = os.base + os.wbase[wave];
     kargs_t p = fresh(ka);
@@ -574,18 +581,21 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     }
 
     // ---- the slice counted two iterations ago goes out (both pending ones when the batch is used up) -----------------
-    if (pb.have) flush(pb, it - 2);
+    if (pd_[kDefer - 1].have) flush(pd_[kDefer - 1], it - kDefer);
     if (!live) {
-      if (pa.have) flush(pa, it - 1);
+#pragma unroll
+      for (uint32_t k = kDefer - 1; k-- > 0;)
+        if (pd_[k].have) flush(pd_[k], it - 1 - k);
       break;
     }
     PSTAMP(tile, 3);
     const Win nwn = window_of(nqy);  // (its two loads are consumed at the top of the next iteration)
 
     // ---- lay the new slice's ids out in the stage, back to back as they will sit in the output -------------------
-    pb = pa;
-    pa = Pending{true, staged, tile, wtotal, (loff << 16) | cnt};
-    uint32_t *const stage = s_stage[wave][it & 1u];
+#pragma unroll
+    for (uint32_t k = kDefer - 1; k > 0; --k) pd_[k] = pd_[k - 1];
+    pd_[0] = Pending{true, staged, tile, wtotal, (loff << 16) | cnt};
+    uint32_t *const stage = s_stage[wave][it % kDefer];
     if (!staged) {
       stage[3 * lane] = (uint32_t)lpos64;
       stage[3 * lane + 1] = (uint32_t)(lpos64 >> 32);
