@@ -1079,9 +1079,10 @@ bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bo
 // (the kernel itself returns at once when k_probe_order found the batch unsorted; the caller launches k_query_fused
 // behind it with the opposite condition).
 bool pipe_dense_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bool unordered) {
+  (void)sort_ids;  // (ascending ids: k_sort_hits orders the CSR afterwards, whichever kernel wrote it)
   const char *env = std::getenv("BIVX_PIPE");
   const int mode = env ? std::atoi(env) : 1;
-  if (!mode || unordered || sort_ids || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
+  if (!mode || unordered || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
   if (v.nslots > (1u << 28)) return false;
   if (q < (size_t)4 * 512 * kPTile && mode != 2) return false;
   return cap > (uint64_t)6 * q;

@@ -184,6 +184,11 @@ def test_many_ids_per_query_position_sorted_batches(oracle, order):
         H, ((off_p, hits_p), (off_f, hits_f)) = _both(idx, to(qlo), to(qhi))
         assert H > 10 * qlo.size
         assert np.array_equal(off_p, off_f) and np.array_equal(hits_p[:H], hits_f[:H])
+        # ascending ids: k_sort_hits orders the CSR behind whichever kernel wrote it
+        H1, ((off_s, hits_s), (off_fs, hits_fs)) = _both(idx, to(qlo), to(qhi), sort_by_id=True)
+        assert np.array_equal(off_s, off_f) and np.array_equal(hits_s[:H], hits_fs[:H])
+        seg = np.repeat(np.arange(qlo.size), np.diff(off_f))
+        assert np.array_equal(hits_s[:H], hits_f[:H][np.lexsort((hits_f[:H], seg))])
         cap = H // 2
         H2, ((off_c, hits_c), _) = _both(idx, to(qlo), to(qhi), cap=cap, workspace=True)
         assert np.array_equal(off_c, off_f) and np.array_equal(hits_c[:cap], hits_f[:cap])
