@@ -259,6 +259,47 @@ def test_edge_coordinates_through_the_pipelined_kernel(oracle, by_id):
         assert np.array_equal(np.sort(hits_p[off_p[i]:off_p[i + 1]]), np.nonzero(m)[0])
 
 
+def test_slice_totals_beyond_32_bits_in_the_pipelined_kernels():
+    """Chromosome-wide queries over 4.2 M nested intervals among point queries: a lane with more than 2^22 hits sends its
+    slice through the 64-bit scan, and a tile's total passes 2^32. Counts and offsets must be exact through
+    k_query_pipe (zero capacity) and, for the many-ids form, through k_query_pipe_dense on the same batch sorted."""
+    import torch
+    from binary_amd import IntervalIndex
+    dev = torch.device("cuda:0")
+    n, q = 4_200_000, 20_000
+    low = np.zeros(n, np.uint32)
+    high = np.arange(1000, 1000 + n, dtype=np.uint32)
+    rng = np.random.default_rng(1)
+    qlo = rng.integers(2000, 1000 + n, q).astype(np.uint32)       # a point query at x hits the intervals with high >= x
+    qhi = qlo.copy()
+    wide = np.sort(rng.permutation(q)[:1100])
+    qlo[wide] = 0
+    qhi[wide] = 1000                                               # everything: 4.2 M hits each, 4.6 G in all
+    exp = np.where(qlo == 0, n, 1000 + n - qlo.astype(np.int64))
+    exp_off = np.concatenate([[0], np.cumsum(exp)])
+    assert exp_off[-1] > 2 ** 32
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        for mode in (2, 0):
+            with _env(BIVX_PIPE=mode):
+                off = idx.count_overlaps_device(to(qlo), to(qhi))
+                idx.stream_status()
+            assert np.array_equal(off.cpu().numpy(), exp_off), mode
+        # many ids per query, position-sorted, a hit buffer far too small: offsets stay exact, nothing beyond it is written
+        p = np.argsort(qlo, kind="stable")
+        with _env(BIVX_PIPE=2):
+            assert idx.query_kernel_name(q, 10 * q).startswith("k_query_pipe_dense")
+            o = torch.empty(q + 1, dtype=torch.int64, device=dev)
+            h = torch.full((10 * q + 64,), -1, dtype=torch.int32, device=dev)
+            idx.query_device(to(qlo[p]), to(qhi[p]), o, h[:10 * q])
+            idx.stream_status()
+        assert np.array_equal(o.cpu().numpy(), np.concatenate([[0], np.cumsum(exp[p])]))
+        assert (h[10 * q:] == -1).all() and (h[:10 * q] >= 0).all()
+        assert idx.stats()["prefix_timeouts"] == 0
+
+
 def test_every_slice_of_a_large_batch_listed():
     """4 584 tiles whose slices all overflow their stage (5.6 ids per query: ~360 per wavefront against 320) while the
     capacity still says "at most 6 per query": 68 760 listed slices — the list must hold 15 entries per tile, not one
