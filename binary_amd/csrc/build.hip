@@ -76,6 +76,20 @@ __global__ __launch_bounds__(kThreads) void k_max_u32(const uint32_t *__restrict
   if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
 }
 
+// largest number of slots any directory cell holds: max over e of table[e + 1] - table[e] (a segment's entries end with
+// its last slot + 1, which is where the next segment's begin: the difference across a boundary is 0)
+__global__ __launch_bounds__(kThreads) void k_max_cell(const uint32_t *__restrict__ table, size_t nentries,
+                                                       uint32_t *__restrict__ out) {
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i + 1 < nentries; i += (size_t)gridDim.x * kThreads) {
+    const uint32_t a = table[i], b = table[i + 1];
+    m = max(m, b > a ? b - a : 0u);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, kWave));
+  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
+}
+
 __global__ __launch_bounds__(kThreads) void k_max_u8(const uint8_t *__restrict__ in, size_t n,
                                                      uint32_t *__restrict__ out) {
   uint32_t m = 0;
@@ -310,6 +324,14 @@ inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0) {
 }
 
 }  // namespace
+
+int launch_max_cell(const uint32_t *d_table, size_t nentries, uint32_t *d_out, hipStream_t s) {
+  BIVX_HIP(hipMemsetAsync(d_out, 0, 4, s));
+  if (nentries < 2) return 0;
+  hipLaunchKernelGGL(k_max_cell, dim3(grid_for(nentries, kThreads * 8, 2048)), dim3(kThreads), 0, s, d_table, nentries, d_out);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
 
 int launch_max_u32(const uint32_t *d_in, size_t n, uint32_t *d_out, hipStream_t s) {
   BIVX_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t), s));

@@ -54,6 +54,7 @@ struct bivx_index {
   uint32_t nchrom = 0, nseg = 0, ntypes = 1;
   std::vector<uint32_t> max_segs;      // per row: most segments any one chromosome has
   uint64_t nentries = 0;
+  uint32_t max_cell = 0;  // most slots in any directory cell (positional hotspots)
   size_t built_n = 0;
   double build_ms = 0.0;
   // prefix workspaces of bivx_query_dev calls made without a caller workspace: one per stream (calls on one
@@ -386,6 +387,7 @@ IndexView view_of(const bivx_index *idx, uint32_t svtype = 0) {
   v.nseg = idx->nseg;
   v.max_segs = row < idx->max_segs.size() ? idx->max_segs[row] : 0;
   v.nslots = idx->built_n < 0xFFFFFFFFull ? (uint32_t)idx->built_n : 0xFFFFFFFFu;
+  v.max_cell = idx->max_cell;
   v.flt_kind = BIVX_FILTER_NONE;
   v.flt_dist = 0;
   v.flt_strand = 0;
@@ -619,6 +621,7 @@ int bivx_build(bivx_index *idx) {
 
   // 1. number of chromosome ids
   uint32_t *d_scalar = nullptr;
+  uint32_t max_cell = 0;  // (read back at the end of the build)
   BIVX_TRY(tmp.alloc(&d_scalar, 1));
   BIVX_TRY(launch_max_u32(idx->d_chrom, n, d_scalar, s));
   uint32_t max_chrom = 0;
@@ -724,6 +727,8 @@ int bivx_build(bivx_index *idx) {
     BIVX_HIP(hipMalloc((void **)&idx->d_table, ((size_t)plan.nentries + 3) * 4));
     BIVX_HIP(hipMemsetAsync(idx->d_table + plan.nentries, 0xFF, 3 * 4, s));
     BIVX_TRY(launch_build_table(idx->d_se, idx->d_seg, nseg, idx->d_table, plan.nentries, s));
+    BIVX_TRY(launch_max_cell(idx->d_table, plan.nentries, d_scalar, s));
+    BIVX_HIP(hipMemcpyAsync(&max_cell, d_scalar, 4, hipMemcpyDeviceToHost, s));
     // 8. packed (record, id) pairs for the segments that allow them (+2 spare: read two at a time)
     BIVX_HIP(hipMalloc((void **)&idx->d_rec, (n + 2) * sizeof(uint2)));
     BIVX_HIP(hipMemsetAsync(idx->d_rec + n, 0, 2 * sizeof(uint2), s));
@@ -735,6 +740,7 @@ int bivx_build(bivx_index *idx) {
   idx->ntypes = ntypes;
   idx->max_segs = std::move(max_segs);
   idx->nentries = plan.nentries;
+  idx->max_cell = max_cell;
   idx->built = true;
   idx->built_n = n;
   idx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

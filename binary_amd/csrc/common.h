@@ -59,6 +59,7 @@ struct IndexView {
   uint32_t nseg;
   uint32_t max_segs;          // most segments any one chromosome has (for the selected type)
   uint32_t nslots;            // sorted slots (= intervals built) — saturates at 2^32 - 1
+  uint32_t max_cell;          // most slots any directory cell holds (positional hotspots make this large)
   // optional post-filter fused into the enumeration (bivx_filter): a candidate must pass it as well
   uint32_t flt_kind;          // BIVX_FILTER_*
   uint32_t flt_dist;
@@ -120,6 +121,7 @@ int exclusive_scan_u32_u32(const uint32_t *d_in, uint32_t *d_out, size_t n, void
 int launch_bin_stats(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n,
                      uint32_t nchrom, BinStats *d_stats, hipStream_t s);
 int launch_max_u32(const uint32_t *d_in, size_t n, uint32_t *d_out, hipStream_t s);
+int launch_max_cell(const uint32_t *d_table, size_t nentries, uint32_t *d_out, hipStream_t s);
 int launch_max_u8(const uint8_t *d_in, size_t n, uint32_t *d_out, hipStream_t s);
 // vchrom[i] = chrom[i] * ntypes + svtype[i] (chrom may be nullptr: all 0)
 int launch_make_vchrom(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t ntypes, uint32_t *d_vchrom,

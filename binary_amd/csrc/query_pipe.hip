@@ -49,6 +49,7 @@ constexpr uint32_t kPStage = kDefer == 2 ? 320 : 640 / kDefer;   // ids per wave
 #define BIVX_FILL_BLOCKS 256
 #endif
 constexpr unsigned kFillBlocks = BIVX_FILL_BLOCKS;  // workgroups (of four wavefronts) of k_fill_slices
+constexpr uint32_t kMaxCellForPipe = 64;  // indexes with a fuller directory cell than this stay on k_query_fused
 constexpr uint32_t kPKeep = 8;      // ids kept per query while counting (a wavefront's 64 x 8 slots are its slab too)
 
 // Diagnostic build only (-DBIVX_STAMPS): wall-clock stamps of worker 0, written to a buffer no other code reads.
@@ -1068,6 +1069,10 @@ bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bo
   const int mode = env ? std::atoi(env) : 1;
   if (!mode || unordered || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
   if (v.nslots > (1u << 28)) return false;  // (32-bit byte offsets into the records, lanes_mask32)
+  // Positional hotspots (thousands of intervals starting inside one directory cell) make single slices take hundreds of
+  // microseconds; a tile here waits for all fifteen of its slices, k_query_fused's tiles wait for nobody but their
+  // predecessors' totals (tools/clustered_bench.py, zero-capacity count: 1.32 ms here, 0.78 there)
+  if (v.max_cell > kMaxCellForPipe && mode != 2) return false;
   // a pipeline has to fill and drain: below about 0.7 M queries (1.4 tiles per resident workgroup) k_query_fused is
   // the faster one (0.25 M: 19.7 against 23.7 us, 0.5 M: 32 / 35, 0.75 M: 45 / 43, 1 M: 54 / 49, 1.3 M: 70 / 60)
   if (q < (size_t)768 * 1024 && mode != 2) return false;
@@ -1083,7 +1088,7 @@ bool pipe_dense_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_i
   const char *env = std::getenv("BIVX_PIPE");
   const int mode = env ? std::atoi(env) : 1;
   if (!mode || unordered || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
-  if (v.nslots > (1u << 28)) return false;
+  if (v.nslots > (1u << 28) || (v.max_cell > kMaxCellForPipe && mode != 2)) return false;
   if (q < (size_t)4 * 512 * kPTile && mode != 2) return false;
   return cap > (uint64_t)6 * q;
 }
