@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
   const uint64_t pos = s_base + local;
   {
     if (q < q_end) {
-      offsets[q] = pos;
+      stream_store(offsets + q, pos);
       if (U) counts[q] = cnt;
       else if (q == q_end - 1) offsets[q_end] = pos + cnt;
     }
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
         const uint32_t nthis = __shfl(loff + cnt, (int)next - 1, kWave) - base;
         for (uint32_t i = lane; i < nthis; i += kWave) {
           const uint64_t p = wpos0 + base + i;
-          if (p < cap) hits[p] = outb[i];
+          if (p < cap) stream_store(hits + p, outb[i]);
         }
         wave_sync_lds();
         first = next;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
         const uint32_t nthis = wtotal - base < kStage ? wtotal - base : kStage;
         for (uint32_t i = lane; i < nthis; i += kWave) {
           const uint64_t p = wpos0 + base + i;
-          if (p < cap) hits[p] = buf[i];
+          if (p < cap) stream_store(hits + p, buf[i]);
         }
         wave_sync_lds();
       }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
       // few ids per lane (or a wavefront that holds general-path queries): every lane stores its own list
       if (rp.ok) {
         replay(0u, cnt, [&](uint32_t k, uint32_t id) {
-          if (pos + k < cap) hits[pos + k] = id;
+          if (pos + k < cap) stream_store(hits + (pos + k), id);
         });
         qy.nseg = 0;
       }

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     uint64_t *off = p->a.offsets;
     if (pd.staged) {
       if (q < q_end) {
-        off[q] = wpos0 + (pd.state >> 16);
+        stream_store(off + q, wpos0 + (pd.state >> 16));
         if (q == q_end - 1) off[q_end] = wpos0 + (pd.state >> 16) + (pd.state & 0xFFFFu);
       }
       const uint64_t cap = p->a.cap;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
                             (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wpos0 >> 32)) << 32;
         uint32_t *const out = p->a.hits + wp;
         const uint32_t lim = cap > wp ? (cap - wp < pd.wtotal ? (uint32_t)(cap - wp) : pd.wtotal) : 0u;
-        for (uint32_t i = tid() & (kWave - 1); i < lim; i += kWave) out[i] = stage[i];
+        for (uint32_t i = tid() & (kWave - 1); i < lim; i += kWave) stream_store(out + i, stage[i]);
       }
     } else {
       // an unstaged slice kept (list offset, count) per lane in its stage; its ids are k_fill_slices' business
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
     if (pd.slab) {
       const uint32_t loff = pd.st >> 15, cnt = pd.st & 127u;
       if (q < q_end) {
-        off[q] = wpos0 + loff;
+        stream_store(off + q, wpos0 + loff);
         if (q == q_end - 1) off[q_end] = wpos0 + loff + cnt;
       }
       if (ids) {
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
           wave_sync_lds();
           const uint32_t n = pd.wtotal - r0 < kDRound ? pd.wtotal - r0 : kDRound;
           const uint32_t lim = room > r0 ? (room - r0 < n ? room - r0 : n) : 0u;
-          for (uint32_t i = tid() & (kWave - 1); i < lim; i += kWave) out[r0 + i] = stage[i];
+          for (uint32_t i = tid() & (kWave - 1); i < lim; i += kWave) stream_store(out + r0 + i, stage[i]);
           wave_sync_lds();
         }
       }
