@@ -383,6 +383,8 @@ __device__ __forceinline__ void wave_sync_lds() {
 // The batch's own streams — queries in, offsets and ids out — are touched once: non-temporal, so that they do not
 // push the index's lines (which random queries come back to) out of L2 and the Infinity Cache. Config 3 moves 330 MB of
 // them per batch next to a 212 MB index: 0.361 -> 0.333 ms in generation order, 0.182 -> 0.170 position-sorted.
+// Only for stores a wavefront makes line by line (offsets, ids out of a stage): a lane storing its own list four bytes
+// at a time needs L2 to merge the pieces — non-temporal there doubled the SV-like spectra's times.
 template <typename T>
 __device__ __forceinline__ T stream_load(const T *p) {
   return __builtin_nontemporal_load(p);

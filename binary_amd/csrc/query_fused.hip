@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
       // few ids per lane (or a wavefront that holds general-path queries): every lane stores its own list
       if (rp.ok) {
         replay(0u, cnt, [&](uint32_t k, uint32_t id) {
-          if (pos + k < cap) stream_store(hits + (pos + k), id);
+          if (pos + k < cap) hits[pos + k] = id;
         });
         qy.nseg = 0;
       }
