@@ -171,6 +171,6 @@ int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const 
                             int flags, uint32_t seq, hipStream_t s);
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
-                      int flags, uint32_t sort_seq, hipStream_t s);
+                      int flags, uint32_t sort_seq, uint32_t *d_counts, uint64_t *d_total, hipStream_t s);
 
 }  // namespace bivx

@@ -452,31 +452,29 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
   uint64_t *ws = static_cast<uint64_t *>(d_ws);
   // ordered output: a launch is limited to the tiles one prefix sweep covers; unordered output has no such limit
   // (only the departure count's 20 bits in ws[kWsDone])
-  unsigned max_tiles = unordered ? (1u << 19) : kFMaxTiles;
+  unsigned max_tiles = unordered ? (1u << 19) : kFMaxTiles, max_tiles_pipe = kFMaxTiles;
   if (const char *e = std::getenv("BIVX_MAX_TILES_PER_LAUNCH")) {  // test knob: forces the chained-launch path
     const long v = std::atol(e);
     if (v >= 1 && v < (long)max_tiles) max_tiles = (unsigned)v;
+    if (v >= 1 && v < (long)max_tiles_pipe) max_tiles_pipe = (unsigned)v;
   }
-  // the common case (one segment per chromosome, no filter, index order, few ids per query) has a pipelined kernel
-  // with tiles of its own size
-  const bool use_pipe = pipe_eligible(v, q, cap, sort_ids, unordered);
+  // the common case (one segment per chromosome, no filter, few ids per query) has a pipelined kernel with tiles of its
+  // own size (begin / count output through it is one launch: there is no entry q_end to chain launches through)
+  const size_t pipe_tile = pipe_queries_per_launch() / kFMaxTiles;
+  const bool use_pipe = pipe_eligible(v, q, cap, sort_ids, unordered) && !(unordered && q > pipe_tile * max_tiles_pipe);
   // ... and so has the case of many ids per query if the batch is position-sorted, which a device-side probe finds out:
   // both kernels are launched, one of them returns at once
   const bool try_dense = !use_pipe && pipe_dense_eligible(v, q, cap, sort_ids, unordered);
-  size_t per_launch = (size_t)max_tiles * kFTile;
-  if (use_pipe || try_dense) {
-    const size_t pp = pipe_queries_per_launch() / kFMaxTiles * max_tiles;
-    per_launch = pp;
-  }
+  const size_t per_launch = use_pipe || try_dense ? pipe_tile * max_tiles_pipe : (size_t)max_tiles * kFTile;
   // caller's workspace: zeroed in front of every launch (ordered output), or once per call (unordered output:
   // the running total lives in it across the call's launches)
-  if (!self_clean && unordered) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));
+  if (!self_clean && unordered && !use_pipe) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));
   for (size_t q0 = 0; q0 < q; q0 += per_launch) {
     const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
     const size_t tile_q = use_pipe ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
     const unsigned tiles = (unsigned)((q1 - q0 + tile_q - 1) / tile_q);
     const size_t tile_small = use_pipe || try_dense ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
-    if (!self_clean && !unordered)
+    if (!self_clean && (!unordered || use_pipe))
       BIVX_HIP(hipMemsetAsync(d_ws, 0, ((q1 - q0 + tile_small - 1) / tile_small + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
     const dim3 grid(tiles), block(kFThreads);
     const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
@@ -503,7 +501,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     }
     if (use_pipe) {
       if (int rc = launch_query_pipe(v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, flags,
-                                     sort_ids ? seq : 0u, s))
+                                     sort_ids ? seq : 0u, d_counts, d_total, s))
         return rc;
     } else {
 #define BIVX_LAUNCH_FUSED_V(L, FL, SO, MSV, UV)                                                               \

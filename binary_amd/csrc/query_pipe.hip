@@ -72,6 +72,10 @@ struct PipeArgs {
   uint32_t ntiles;
   int flags;
   uint32_t seq;   // != 0: ids ascending inside every query
+  // begin / count output (bivx_query_dev_u): `offsets` receives every query's first position only (no entry q_end),
+  // `counts` its number of ids and `total_out` the batch's total
+  uint32_t *counts;
+  uint64_t *total_out;
 };
 
 // The kernel's arguments stay where the launch put them — the kernarg segment, constant memory — and are re-read
@@ -441,7 +445,9 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     if (pd.staged) {
       if (q < q_end) {
         stream_store(off + q, wpos0 + (pd.state >> 16));
-        if (q == q_end - 1) off[q_end] = wpos0 + (pd.state >> 16) + (pd.state & 0xFFFFu);
+        uint32_t *counts = p->a.counts;
+        if (counts) stream_store(counts + q, pd.state & 0xFFFFu);
+        if (q == q_end - 1) *(counts ? p->a.total_out : off + q_end) = wpos0 + (pd.state >> 16) + (pd.state & 0xFFFFu);
       }
       const uint64_t cap = p->a.cap;
       if (cap != 0) {
@@ -458,7 +464,9 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       const uint32_t c = stage[3 * lane + 2];
       if (q < q_end) {
         off[q] = wpos0 + lp;
-        if (q == q_end - 1) off[q_end] = wpos0 + lp + c;
+        uint32_t *counts = p->a.counts;
+        if (counts) counts[q] = c;
+        if (q == q_end - 1) *(counts ? p->a.total_out : off + q_end) = wpos0 + lp + c;
       }
       if (lane == 0) {
         uint64_t *ws = p->a.ws;
@@ -1063,11 +1071,21 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
 }  // namespace
 
 // true if the pipelined kernel handled the launch (the caller falls back to k_query_fused otherwise)
+static int mode_forced() {
+  const char *env = std::getenv("BIVX_PIPE");
+  return env ? std::atoi(env) : 1;
+}
+
 bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bool unordered) {
+  // (begin / count output: the ordered CSR is a valid answer, and since the pipelined kernel it is the faster one —
+  // config 3 0.33 against 0.35 ms; one launch only, there is no entry q_end to chain launches through)
+  // Only for large batches: at 1 M queries k_query_fused<U>, whose tiles wait for nobody, takes 43 us (22 position-sorted)
+  // against 48 (32) here.
+  if (unordered && (sort_ids || q > (size_t)kFMaxTiles * kPTile || (q < ((size_t)4 << 20) && mode_forced() != 2))) return false;
   // BIVX_PIPE: 0 = never, 1 = when eligible (default), 2 = also for small batches (tests)
   const char *env = std::getenv("BIVX_PIPE");
   const int mode = env ? std::atoi(env) : 1;
-  if (!mode || unordered || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
+  if (!mode || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
   if (v.nslots > (1u << 28)) return false;  // (32-bit byte offsets into the records, lanes_mask32)
   // Positional hotspots (thousands of intervals starting inside one directory cell) make single slices take hundreds of
   // microseconds; a tile here waits for all fifteen of its slices, k_query_fused's tiles wait for nobody but their
@@ -1097,7 +1115,7 @@ size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }
 
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
-                      int flags, uint32_t sort_seq, hipStream_t s) {
+                      int flags, uint32_t sort_seq, uint32_t *d_counts, uint64_t *d_total, hipStream_t s) {
   const unsigned tiles = (unsigned)((q1 - q0 + kPTile - 1) / kPTile);
   unsigned wgs = 512;
   {
@@ -1110,7 +1128,7 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
     }
   }
-  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, sort_seq};
+  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, sort_seq, d_counts, d_total};
   if (sort_seq)
     hipLaunchKernelGGL(k_query_pipe<true>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   else
@@ -1138,7 +1156,7 @@ int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const 
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
     }
   }
-  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, seq};
+  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, seq, nullptr, nullptr};
   hipLaunchKernelGGL(k_probe_order, dim3(1), dim3(256), 0, s, d_qchrom, d_qlow, q0, q1, ws, seq);
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   a.seq = 0;  // (k_fill_slices: index order)

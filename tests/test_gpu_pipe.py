@@ -300,6 +300,41 @@ def test_slice_totals_beyond_32_bits_in_the_pipelined_kernels():
         assert idx.stats()["prefix_timeouts"] == 0
 
 
+def test_begin_count_output_through_the_pipelined_kernel():
+    """bivx_query_dev_u asks for per-query (begin, count) in any layout; the ordered CSR is one, and on batches the
+    pipelined kernel takes it is the faster answer: begin[q] = offsets[q], count[q] = the list's length, total = H —
+    staged slices, listed slices (a stage overflow) and a caller workspace included."""
+    import torch
+    from binary_amd import IntervalIndex, synth
+    d = synth.gen_genome(300_000, 200_003, 1000)
+    qc, qlo, qhi = d["qchrom"], d["qlow"], d["qhigh"]
+    qlo[5000:5400] = 1_500_000 + np.arange(400)      # neighbouring long queries: their wavefronts' lists overflow a stage
+    qhi[5000:5400] = qlo[5000:5400] + 40_000
+    qc[5000:5400] = 0
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(d["low"], d["high"], d["chrom"])
+        idx.build()
+        d_qlo, d_qhi, d_qc = to(qlo), to(qhi), to(qc)
+        with _env(BIVX_PIPE=0):
+            ref_off, ref_hits = idx.find_overlaps_device(d_qlo, d_qhi, d_qc)
+        H, q = int(ref_off[-1].item()), qlo.size
+        for workspace in (False, True):
+            with _env(BIVX_PIPE=2):
+                beg = torch.full((q,), -1, dtype=torch.int64, device=dev)
+                cnt = torch.full((q,), -1, dtype=torch.int32, device=dev)
+                tot = torch.full((1,), -1, dtype=torch.int64, device=dev)
+                hits = torch.full((H,), -1, dtype=torch.int32, device=dev)
+                ws = torch.empty(idx.query_workspace_bytes(q), dtype=torch.uint8, device=dev) if workspace else None
+                for _ in range(2):
+                    idx.query_device_unordered(d_qlo, d_qhi, beg, cnt, hits, tot, workspace=ws, qchrom=d_qc)
+                idx.stream_status()
+            assert int(tot.item()) == H
+            assert torch.equal(beg, ref_off[:-1]) and torch.equal(cnt.to(torch.int64), ref_off[1:] - ref_off[:-1])
+            assert torch.equal(hits, ref_hits)
+
+
 def test_every_slice_of_a_large_batch_listed():
     """4 584 tiles whose slices all overflow their stage (5.6 ids per query: ~360 per wavefront against 320) while the
     capacity still says "at most 6 per query": 68 760 listed slices — the list must hold 15 entries per tile, not one
