@@ -247,7 +247,8 @@ int bivx_query_dev_s(const bivx_index *idx, const uint32_t *d_qchrom, const uint
 /* The single pass without the canonical CSR: for callers that only need every query's hits, not one monotone
  * offsets array (sv2nl consumes one NL record's hits at a time, mapper.hpp:205-231). A workgroup reserves the
  * output range of its 1024 queries with one atomic add and waits for nobody, so the cross-workgroup prefix —
- * about a sixth of bivx_query_dev's time at 1 M queries, more on larger batches — disappears. Query i's hits
+ * about a tenth of bivx_query_dev's time at 1 M queries — disappears. (On batches of 4 M queries and more the
+ * pipelined kernel's ordered CSR is the faster answer and is what this call returns: d_begin = the offsets.) Query i's hits
  * are d_hit_ids[d_begin[i] .. d_begin[i] + d_count[i]) in index order; ranges of different workgroups lie in
  * the buffer in arrival order (not reproducible between calls), the sets are exactly those of bivx_query_dev.
  * *d_total receives the number of ids reserved; when it exceeds hit_capacity only slots below the capacity were
