@@ -335,6 +335,56 @@ def test_begin_count_output_through_the_pipelined_kernel():
             assert torch.equal(hits, ref_hits)
 
 
+def test_two_streams_query_the_same_index_at_once():
+    """const calls are mutually thread-safe (the reference's mappers query their trees concurrently,
+    mapper.cpp:130-141): two host threads, a stream each, pipelined launches that compete for the CUs — a workgroup of
+    one launch may have to wait for the other launch's workgroups to leave before it can start. Every result must be
+    the single-stream one."""
+    import threading
+    import torch
+    from binary_amd import IntervalIndex, synth
+    d = synth.gen_genome(500_000, 400_000, 1000)
+    dev = torch.device("cuda:0")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    with IntervalIndex(0) as idx, _env(BIVX_PIPE=2):
+        idx.insert_node(d["low"], d["high"], d["chrom"])
+        idx.build()
+        halves = []
+        for sl in (slice(0, 200_000), slice(200_000, 400_000)):
+            qc, ql, qh = to(d["qchrom"][sl]), to(d["qlow"][sl]), to(d["qhigh"][sl])
+            off, hits = idx.find_overlaps_device(ql, qh, qc)
+            halves.append((qc, ql, qh, off, hits))
+        torch.cuda.synchronize()
+        errors = []
+
+        def work(k):
+            try:
+                qc, ql, qh, ref_off, ref_hits = halves[k]
+                st = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st):
+                    off = torch.empty_like(ref_off)
+                    hits = torch.empty_like(ref_hits)
+                    for _ in range(25):
+                        off.fill_(-1)
+                        hits.fill_(-1)
+                        idx.query_device(ql, qh, off, hits, qchrom=qc)
+                        st.synchronize()
+                        idx.stream_status()
+                        if not (torch.equal(off, ref_off) and torch.equal(hits, ref_hits)):
+                            errors.append(f"thread {k}: result differs")
+                            return
+            except Exception as e:  # noqa: BLE001
+                errors.append(f"thread {k}: {type(e).__name__}: {e}")
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+        assert idx.stats()["prefix_timeouts"] == 0
+
+
 def test_every_slice_of_a_large_batch_listed():
     """4 584 tiles whose slices all overflow their stage (5.6 ids per query: ~360 per wavefront against 320) while the
     capacity still says "at most 6 per query": 68 760 listed slices — the list must hold 15 entries per tile, not one
