@@ -155,7 +155,8 @@ int bivx_fill_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_
 /* Single pass for callers that already own a hit buffer (steady-state serving): one kernel counts, chains
  * the prefix across workgroups and fills. d_offsets[q] receives the true total H even when H >
  * hit_capacity; in that case only the first hit_capacity slots of the CSR were written and the caller
- * repeats the call (or bivx_fill_dev) with a buffer of at least H entries. d_workspace: NULL (the index keeps
+ * repeats the call (or bivx_fill_dev) with a buffer of at least H entries (with ascending ids the one list that
+ * straddles the capacity holds some of its ids below it, not necessarily its smallest). d_workspace: NULL (the index keeps
  * one 4.5 MB workspace per stream, which needs no clearing between calls), or bivx_query_workspace_bytes(q)
  * bytes of caller scratch (cleared by a memset in front of every launch). */
 size_t bivx_query_workspace_bytes(size_t q);
