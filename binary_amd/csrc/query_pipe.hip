@@ -44,7 +44,7 @@ constexpr uint32_t kRing = 8;                  // tile slots in LDS
 #endif
 constexpr uint32_t kDefer = BIVX_DEFER;  // iterations between counting a slice and writing it out (experiments: 1, 3)
 static_assert(kDefer >= 1 && kDefer <= 3, "deferral depth");
-constexpr uint32_t kPStage = kDefer == 2 ? 320 : 640 / kDefer;   // ids per wavefront stage (there are two: a slice waits two iterations for its base)
+constexpr uint32_t kPStage = kDefer == 2 ? 320 : (640 / kDefer) & ~3u;   // ids per wavefront stage (there are two: a slice waits two iterations for its base)
 #ifndef BIVX_FILL_BLOCKS
 #define BIVX_FILL_BLOCKS 256
 #endif
@@ -119,6 +119,16 @@ __device__ __forceinline__ void lds_wait_eq(const uint32_t *p, uint32_t x) {
   // (polls cost issue slots the other wavefronts of the SIMD could use: a wait of a few microseconds is not polled
   // every sixty nanoseconds)
   while (lds_load(p) != x) __builtin_amdgcn_s_sleep(4);
+}
+
+// `n` ids from a wavefront's stage (16-byte aligned) to consecutive output slots: four per lane and instruction (the
+// output address is only 4-byte aligned, which gfx950's unaligned access mode allows), then the last n % 4 one by one.
+__device__ __forceinline__ void stage_to_output(const uint32_t *stage, uint32_t *out, uint32_t n, uint32_t lane) {
+  typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4)));
+  const uint32_t n4 = n & ~3u;
+  for (uint32_t i = lane * 4u; i < n4; i += kWave * 4u)
+    __builtin_nontemporal_store(*reinterpret_cast<const u32x4_a16 *>(stage + i), reinterpret_cast<u32x4_a4 *>(out + i));
+  if (n4 + lane < n) stream_store(out + n4 + lane, stage[n4 + lane]);
 }
 
 // A query's candidate window, worked out ahead of the counting (bucket directory probe): slots [a, b), the coordinate of
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ TileSlot s_slot[kRing];
   __shared__ uint4 s_keep[kWorkers * kWave * (kPKeep / 4)];   // keep slots / slabs of the slice being counted
-  __shared__ uint32_t s_stage[kWorkers][kDefer][kPStage];     // ids of the pending slices, laid out as in the output
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWorkers][kDefer][kPStage];     // ids of the pending slices, laid out as in the output
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
                             (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wpos0 >> 32)) << 32;
         uint32_t *const out = p->a.hits + wp;
         const uint32_t lim = cap > wp ? (cap - wp < pd.wtotal ? (uint32_t)(cap - wp) : pd.wtotal) : 0u;
-        for (uint32_t i = tid() & (kWave - 1); i < lim; i += kWave) stream_store(out + i, stage[i]);
+        stage_to_output(stage, out, lim, tid() & (kWave - 1));
       }
     } else {
       // an unstaged slice kept (list offset, count) per lane in its stage; its ids are k_fill_slices' business
@@ -714,7 +724,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ TileSlot s_slot[kRing];
   __shared__ uint4 s_keep[kWorkers * kWave * (kPKeep / 4)];   // the wavefronts' slabs
-  __shared__ uint32_t s_stage[kWorkers][2 * kPStage];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWorkers][2 * kPStage];
   {  // the order probe's verdict: this launch's sequence number if the batch is position-sorted
     kargs_t p = fresh(ka);
     const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(p->a.ws + kWsOrder), __ATOMIC_RELAXED,
@@ -836,34 +846,32 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
         const uint32_t room = cap > wp ? (cap - wp < 0xFFFFFFFFull ? (uint32_t)(cap - wp) : 0xFFFFFFFFu) : 0u;
         const uint2 *s2 = reinterpret_cast<const uint2 *>(slab_of_wave()) + ((pd.st >> 7) & 255u);
         // the mask is walked one 32-bit word at a time (find-first-set and clear-lowest are one and two instructions
-        // on a word, four each on 64 bits)
-        uint32_t mw = (uint32_t)pd.x, mhi = (uint32_t)(pd.x >> 32), jbase = 0;
-        if (mw == 0u) {
-          mw = mhi;
-          mhi = 0u;
-          jbase = 32u;
-        }
-        uint32_t pos = loff;
+        // on a word, four each on 64 bits): first the low word's hits, then the high word's
+        uint32_t m0 = (uint32_t)pd.x, m1 = (uint32_t)(pd.x >> 32);
+        uint32_t done = 0;  // ids this lane has laid out in earlier rounds
         const uint32_t end = loff + cnt;
         for (uint32_t r0 = 0; r0 < pd.wtotal; r0 += kDRound) {
           // a lane's ids enter the stage in order, over one or more consecutive rounds
           const uint32_t stop = end < r0 + kDRound ? end : r0 + kDRound;
-          uint32_t *dst = stage + (pos - r0);
-          while (pos < stop) {
-            const uint32_t jj = (uint32_t)__ffs((int)mw) - 1u;
-            mw &= mw - 1u;
-            *dst++ = s2[jbase + jj].y;
-            ++pos;
-            if (mw == 0u) {
-              mw = mhi;
-              mhi = 0u;
-              jbase = 32u;
+          if (loff + done < stop) {
+            uint32_t *dst = stage + (loff + done - r0);
+            uint32_t *const dstop = stage + (stop - r0);
+            while (m0 != 0u && dst < dstop) {
+              const uint32_t jj = (uint32_t)__ffs((int)m0) - 1u;
+              m0 &= m0 - 1u;
+              *dst++ = s2[jj].y;
             }
+            while (m1 != 0u && dst < dstop) {  // (only once the low word is used up: otherwise dst == dstop)
+              const uint32_t jj = (uint32_t)__ffs((int)m1) - 1u;
+              m1 &= m1 - 1u;
+              *dst++ = s2[32u + jj].y;
+            }
+            done = (uint32_t)(dst - stage) + r0 - loff;
           }
           wave_sync_lds();
           const uint32_t n = pd.wtotal - r0 < kDRound ? pd.wtotal - r0 : kDRound;
           const uint32_t lim = room > r0 ? (room - r0 < n ? room - r0 : n) : 0u;
-          for (uint32_t i = tid() & (kWave - 1); i < lim; i += kWave) stream_store(out + r0 + i, stage[i]);
+          stage_to_output(stage, out + r0, lim, tid() & (kWave - 1));
           wave_sync_lds();
         }
       }
