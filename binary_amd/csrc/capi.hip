@@ -74,6 +74,9 @@ struct bivx_index {
   // of queries otherwise spends more time in hipMalloc / hipFree (which synchronises the device) than on the GPU
   mutable std::mutex cache_mutex;
   mutable std::multimap<size_t, void *> cache_free;  // block size -> block
+  // pinned host blocks mapped into the device (host address, device address), for the few-queries path of
+  // bivx_find_overlaps: the kernel reads the queries and writes offsets and ids straight through them
+  mutable std::vector<std::pair<void *, void *>> mailboxes;
   mutable size_t cache_bytes = 0;
 };
 
@@ -547,6 +550,8 @@ void bivx_destroy(bivx_index *idx) {
   (void)hipDeviceSynchronize();
   for (auto &kv : idx->ws_of_stream) (void)hipFree(kv.second.p);
   if (idx->h_err) (void)hipHostFree(idx->h_err);
+  for (auto &m : idx->mailboxes) (void)hipHostFree(m.first);
+  idx->mailboxes.clear();
   drop_block_cache(idx);
   free_built(idx);
   (void)hipFree(idx->d_chrom);
@@ -1017,6 +1022,43 @@ namespace {
 // and the caller takes the count-then-fill path.
 constexpr size_t kSmallBatch = 2048, kSmallBatchIds = 32;
 constexpr int kSmallBatchOverflow = 1;
+// A mailbox: kMailboxBytes of pinned host memory the device can address. Taken from the index's stock (or allocated),
+// given back when the call is over.
+constexpr size_t kMailboxQueries = 64, kMailboxBytes = 32u << 10;
+struct Mailbox {
+  const bivx_index *idx;
+  void *host = nullptr, *dev = nullptr;
+  explicit Mailbox(const bivx_index *owner) : idx(owner) {
+    {
+      std::lock_guard<std::mutex> lock(idx->cache_mutex);
+      if (!idx->mailboxes.empty()) {
+        host = idx->mailboxes.back().first;
+        dev = idx->mailboxes.back().second;
+        idx->mailboxes.pop_back();
+      }
+    }
+    if (!host) {
+      if (hipHostMalloc(&host, kMailboxBytes, hipHostMallocMapped) != hipSuccess ||
+          hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr;
+      }
+    }
+  }
+  ~Mailbox() {
+    if (!host) return;
+    std::lock_guard<std::mutex> lock(idx->cache_mutex);
+    idx->mailboxes.emplace_back(host, dev);
+  }
+};
+
+// A handful of queries (the facade's per-record calls, interval_tree.hpp:306-334 under mapper.hpp:218): no copies at all.
+// The queries are written into a mailbox, the single-pass kernel reads them and writes offsets and ids through the
+// same mapping, and the stream is synchronised once. Returns kSmallBatchOverflow if the ids did not fit.
+int find_overlaps_tiny(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                       size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+                       uint32_t **hit_ids_out);
+
 int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                         size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
                         uint32_t **hit_ids_out) {
@@ -1060,6 +1102,43 @@ int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uin
     set_error("bivx_find_overlaps: device copy failed");
     return BIVX_E_HIP;
   }
+  *hit_ids_out = out;
+  return 0;
+}
+
+int find_overlaps_tiny(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                       size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+                       uint32_t **hit_ids_out) {
+  Mailbox mb(idx);
+  if (!mb.host) return kSmallBatchOverflow;  // (no mapping to be had: the copying path)
+  hipStream_t s = idx->stream;
+  // layout (u32 words): [qlow | qhigh | qchrom] (3 x 64) [pad] [offsets: 65 x u64] [ids ...]
+  const size_t q_words = 3 * kMailboxQueries, off_words = 2 * (kMailboxQueries + 1);
+  const size_t cap = kMailboxBytes / 4 - q_words - off_words;
+  uint32_t *h = static_cast<uint32_t *>(mb.host), *d = static_cast<uint32_t *>(mb.dev);
+  std::memcpy(h, qlow, q * 4);
+  std::memcpy(h + kMailboxQueries, qhigh, q * 4);
+  if (qchrom) std::memcpy(h + 2 * kMailboxQueries, qchrom, q * 4);
+  uint64_t *d_off = reinterpret_cast<uint64_t *>(d + q_words);
+  const uint64_t *h_off = reinterpret_cast<const uint64_t *>(h + q_words);
+  // (index order from the device; ascending ids, if asked for, are a std::sort over a few short lists below — one
+  // kernel launch less, 5 us of a 28 us call)
+  BIVX_TRY(bivx_query_dev_s(idx, qchrom ? d + 2 * kMailboxQueries : nullptr, d, d + kMailboxQueries, q, filter,
+                            0, d_off, d + q_words + off_words, cap, nullptr, 0, s));
+  BIVX_HIP(hipStreamSynchronize(s));
+  BIVX_TRY(report_device_errors(idx, "bivx_find_overlaps"));
+  const uint64_t total = h_off[q];
+  if (total > cap) return kSmallBatchOverflow;
+  std::memcpy(offsets_out, h_off, (q + 1) * 8);
+  if (total == 0) return 0;
+  uint32_t *out = static_cast<uint32_t *>(std::malloc((size_t)total * sizeof(uint32_t)));
+  if (!out) {
+    set_error("bivx_find_overlaps: out of host memory for %llu hit ids", (unsigned long long)total);
+    return BIVX_E_NOMEM;
+  }
+  std::memcpy(out, h + q_words + off_words, (size_t)total * 4);
+  if (sort_by_id)
+    for (size_t i = 0; i < q; ++i) std::sort(out + h_off[i], out + h_off[i + 1]);
   *hit_ids_out = out;
   return 0;
 }
@@ -1193,7 +1272,10 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
   if (q <= kSmallBatch && (!filter || filter->kind == BIVX_FILTER_NONE)) {
-    int rc = find_overlaps_small(idx, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
+    int rc = kSmallBatchOverflow;
+    if (q <= kMailboxQueries) rc = find_overlaps_tiny(idx, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
+    if (rc == kSmallBatchOverflow)
+      rc = find_overlaps_small(idx, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
     if (rc != kSmallBatchOverflow) return rc;
   }
   TempPool tmp(idx);
@@ -1249,6 +1331,20 @@ int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow
   }
   BIVX_GUARD(idx);
   hipStream_t s = idx->stream;
+  if (q <= kMailboxQueries) {  // a handful of queries (the facade's find_overlap per record): through a mailbox, no copies
+    Mailbox mb(idx);
+    if (mb.host) {
+      uint32_t *h = static_cast<uint32_t *>(mb.host), *d = static_cast<uint32_t *>(mb.dev);
+      std::memcpy(h, qlow, q * 4);
+      std::memcpy(h + kMailboxQueries, qhigh, q * 4);
+      if (qchrom) std::memcpy(h + 2 * kMailboxQueries, qchrom, q * 4);
+      BIVX_TRY(bivx_any_dev(idx, qchrom ? d + 2 * kMailboxQueries : nullptr, d, d + kMailboxQueries, q,
+                            d + 3 * kMailboxQueries, s));
+      BIVX_HIP(hipStreamSynchronize(s));
+      std::memcpy(first_id_out, h + 3 * kMailboxQueries, q * 4);
+      return 0;
+    }
+  }
   TempPool tmp(idx);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
