@@ -1121,10 +1121,13 @@ int find_overlaps_tiny(const bivx_index *idx, const uint32_t *qchrom, const uint
   if (qchrom) std::memcpy(h + 2 * kMailboxQueries, qchrom, q * 4);
   uint64_t *d_off = reinterpret_cast<uint64_t *>(d + q_words);
   const uint64_t *h_off = reinterpret_cast<const uint64_t *>(h + q_words);
-  // (index order from the device; ascending ids, if asked for, are a std::sort over a few short lists below — one
-  // kernel launch less, 5 us of a 28 us call)
-  BIVX_TRY(bivx_query_dev_s(idx, qchrom ? d + 2 * kMailboxQueries : nullptr, d, d + kMailboxQueries, q, filter,
-                            0, d_off, d + q_words + off_words, cap, nullptr, 0, s));
+  // (one wavefront answers the whole call — k_query_tiny: no workspace, no prefix across workgroups; index order from
+  // the device, and ascending ids, if asked for, are a std::sort over a few short lists below)
+  IndexView view;
+  BIVX_TRY(view_with_filter(idx, filter, view));  // (a type selection at most: the caller let no filter kind through)
+  if (launch_query_tiny(view, qchrom ? d + 2 * kMailboxQueries : nullptr, d, d + kMailboxQueries, q, d_off,
+                        d + q_words + off_words, cap, s) != 0)
+    return kSmallBatchOverflow;
   BIVX_HIP(hipStreamSynchronize(s));
   BIVX_TRY(report_device_errors(idx, "bivx_find_overlaps"));
   const uint64_t total = h_off[q];

@@ -148,6 +148,8 @@ int launch_gather_intervals(const uint32_t *d_chrom, const uint32_t *d_low, cons
                             uint32_t *d_h, hipStream_t s);
 
 // ---- query.hip, query_fused.hip ---------------------------------------------------------------------------
+int launch_query_tiny(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                      size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, hipStream_t s);
 int launch_fill(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                 size_t q, const uint64_t *d_offsets, uint32_t *d_hits, hipStream_t s);
 int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,

@@ -63,6 +63,38 @@ __global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restr
   wave_sort_lists<kSortLds, kRankBlock, true>(lds[threadIdx.x >> 6], o0, o1, hits, threadIdx.x & (kWave - 1));
 }
 
+// One wavefront answers up to 64 queries completely — counts, their prefix sum, offsets, ids in index order — for the
+// few-queries host calls (capi.hip, mailbox path): no workspace, no ticket, no second kernel. Two enumerations (count,
+// then fill) of at most 64 windows. offsets[q] receives the total; ids beyond `cap` are not written.
+template <bool LDS_DESC>
+__global__ __launch_bounds__(kWave) void k_query_tiny(IndexView v, const uint32_t *__restrict__ qchrom,
+                                                     const uint32_t *__restrict__ qlow,
+                                                     const uint32_t *__restrict__ qhigh, uint32_t nq,
+                                                     uint64_t *__restrict__ offsets, uint32_t *__restrict__ hits,
+                                                     uint64_t cap) {
+  __shared__ SegDesc s_seg[LDS_DESC ? kLdsSegs : 1];
+  __shared__ uint2 s_cs[LDS_DESC ? kLdsChroms : 1];
+  const SegDesc *segs;
+  const uint2 *cs;
+  stage_descriptors<false>(v, s_seg, s_cs, segs, cs);  // (64 queries: the descriptors are read where they lie)
+  const uint32_t lane = threadIdx.x;
+  const bool valid = lane < nq;
+  const Query qy = load_query<false>(v, cs, qchrom, qlow, qhigh, lane, valid);
+  // (MS = true: the counting enumeration of the one-segment kernels makes a single trip through the segment loop)
+  const uint32_t cnt = enumerate_hits<Mode::Count, false, true>(v, segs, qy, nullptr, 0, 0, nullptr);
+  // 64-bit exclusive prefix over the lanes (a single query may have more than 2^32 / 64 hits)
+  uint64_t incl = cnt;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint64_t o = __shfl_up((unsigned long long)incl, d, kWave);
+    if ((int)lane >= d) incl += o;
+  }
+  const uint64_t pos = incl - cnt;
+  if (valid) offsets[lane] = pos;
+  if (lane == kWave - 1) offsets[nq] = incl;
+  if (cap != 0) (void)enumerate_hits<Mode::Fill, false>(v, segs, qy, hits, pos, cap, nullptr);
+}
+
 template <Mode M>
 int launch_query(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                  size_t q, const uint64_t *d_offsets, uint32_t *d_out, hipStream_t s) {
@@ -83,6 +115,15 @@ int launch_query(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d
 
 
 }  // namespace
+
+int launch_query_tiny(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                      size_t q, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, hipStream_t s) {
+  if (q == 0 || q > (size_t)kWave || v.flt_kind != BIVX_FILTER_NONE) return -1;
+  hipLaunchKernelGGL(k_query_tiny<false>, dim3(1), dim3(kWave), 0, s, v, d_qchrom, d_qlow, d_qhigh, (uint32_t)q,
+                     d_offsets, d_hits, cap);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
 
 int launch_fill(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                 size_t q, const uint64_t *d_offsets, uint32_t *d_hits, hipStream_t s) {
