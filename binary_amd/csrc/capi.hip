@@ -78,6 +78,11 @@ struct bivx_index {
   // bivx_find_overlaps: the kernel reads the queries and writes offsets and ids straight through them
   mutable std::vector<std::pair<void *, void *>> mailboxes;
   mutable size_t cache_bytes = 0;
+  // The host-pointer query entry points all launch on idx->stream and share ONE error block: held from a call's first
+  // launch to its report, so that a thread's synchronisation cannot cover — and its report consume — another thread's
+  // failed kernel (sv2nl runs three mappers on one index). The device work of such calls is serialised by the shared
+  // stream anyway.
+  mutable std::mutex call_mutex;
 };
 
 // the device-pointer entry points address ONE device's memory: a sharded handle has no meaning for them
@@ -403,11 +408,13 @@ IndexView view_of(const bivx_index *idx, uint32_t svtype = 0) {
 // Turns a raised error word into BIVX_E_TIMEOUT, once. Call after a synchronisation that covers the kernels in
 // question. The words are reset and every index-owned workspace is cleared before its next launch.
 int report_device_errors(const bivx_index *idx, const char *who) {
-  volatile uint32_t *e = idx->h_err;
-  const bool timeout = e[kErrTimeout] != 0, dirty = e[kErrWorkspace] != 0;
-  if (!timeout && !dirty) return 0;
-  e[kErrTimeout] = 0;
-  e[kErrWorkspace] = 0;
+  // read-and-clear in one step per word: a flag the device raises between a read and a separate clear would be lost
+  uint32_t *e = idx->h_err;
+  if (__atomic_load_n(&e[kErrTimeout], __ATOMIC_RELAXED) == 0 && __atomic_load_n(&e[kErrWorkspace], __ATOMIC_RELAXED) == 0)
+    return 0;
+  const bool timeout = __atomic_exchange_n(&e[kErrTimeout], 0u, __ATOMIC_ACQ_REL) != 0;
+  const bool dirty = __atomic_exchange_n(&e[kErrWorkspace], 0u, __ATOMIC_ACQ_REL) != 0;
+  if (!timeout && !dirty) return 0;  // (another thread's report took them)
   idx->errors_reported.fetch_add(1);
   {
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
@@ -597,6 +604,13 @@ int bivx_clear(bivx_index *idx) {
   BIVX_GUARD(idx);
   BIVX_HIP(hipStreamSynchronize(idx->stream));
   free_built(idx);
+  if (idx->typed && idx->d_type && idx->n) {
+    // the slots are reused by later appends: an untyped append into them only clears type bytes while `typed` is set,
+    // so bytes left here would label those intervals once a later typed append sets it again
+    BIVX_HIP(hipDeviceSynchronize());  // (typed appends made with bivx_append_typed_dev ran on caller streams)
+    BIVX_HIP(hipMemsetAsync(idx->d_type, 0, idx->n, idx->stream));
+    BIVX_HIP(hipStreamSynchronize(idx->stream));
+  }
   idx->n = 0;
   idx->typed = false;
   return 0;
@@ -1194,6 +1208,7 @@ int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *
     return 0;
   }
   BIVX_GUARD(idx);
+  std::lock_guard<std::mutex> call_lock(idx->call_mutex);  // launch .. report, one call at a time (bivx_index::call_mutex)
   hipStream_t s = idx->stream;
   TempPool tmp(idx);
   DevQueries d;
@@ -1234,6 +1249,7 @@ int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *q
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
+  std::lock_guard<std::mutex> call_lock(idx->call_mutex);  // launch .. report, one call at a time (bivx_index::call_mutex)
   hipStream_t s = idx->stream;
   TempPool tmp(idx);
   DevQueries d;
@@ -1273,6 +1289,7 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
     return 0;
   }
   BIVX_GUARD(idx);
+  std::lock_guard<std::mutex> call_lock(idx->call_mutex);  // launch .. report, one call at a time (bivx_index::call_mutex)
   hipStream_t s = idx->stream;
   if (q <= kSmallBatch && (!filter || filter->kind == BIVX_FILTER_NONE)) {
     int rc = kSmallBatchOverflow;

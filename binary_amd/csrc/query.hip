@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kWave) void k_query_tiny(IndexView v, const uint32_
   const uint32_t lane = threadIdx.x;
   const bool valid = lane < nq;
   const Query qy = load_query<false>(v, cs, qchrom, qlow, qhigh, lane, valid);
-  // (MS = true: the counting enumeration of the one-segment kernels makes a single trip through the segment loop)
+  // (MS = true on purpose: it makes the counting enumeration walk ALL of the chromosome's segments — the MS = false
+  // form is the one-segment kernels' single trip through the segment loop, which would miss every later length class)
   const uint32_t cnt = enumerate_hits<Mode::Count, false, true>(v, segs, qy, nullptr, 0, 0, nullptr);
   // 64-bit exclusive prefix over the lanes (a single query may have more than 2^32 / 64 hits)
   uint64_t incl = cnt;

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -39,17 +40,47 @@ struct ShardedState {
 
 namespace {
 
+// No C++ exception may cross the C ABI (include/bivx.h): everything below that allocates (std::vector, std::thread)
+// runs inside this, which turns a throw into a status code and an error text.
+template <typename F>
+int no_throw(const char *who, F &&f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    set_error("%s: out of host memory", who);
+    return BIVX_E_NOMEM;
+  } catch (const std::exception &e) {
+    set_error("%s: %s", who, e.what());
+    return BIVX_E_HIP;
+  } catch (...) {
+    set_error("%s: unknown failure", who);
+    return BIVX_E_HIP;
+  }
+}
+
 template <typename F>
 int on_every_shard(const ShardedState *st, F &&f) {
   const size_t k = st->shard.size();
   std::vector<int> rc(k, 0);
   std::vector<std::string> err(k);
   std::vector<std::thread> th;
-  for (size_t s = 0; s < k; ++s)
-    th.emplace_back([&, s] {
-      rc[s] = f(s);
-      if (rc[s] != 0) err[s] = bivx_last_error();  // thread-local text: carry it over to the caller's thread
-    });
+  th.reserve(k);
+  try {
+    for (size_t s = 0; s < k; ++s)
+      th.emplace_back([&, s] {
+        // (an exception that left a thread's body would end the process: std::terminate)
+        rc[s] = no_throw("shard thread", [&] { return f(s); });
+        if (rc[s] != 0) {
+          try {
+            err[s] = bivx_last_error();  // thread-local text: carry it over to the caller's thread
+          } catch (...) {
+          }
+        }
+      });
+  } catch (...) {  // std::system_error: no more threads to be had — the ones that started must still be joined
+    for (auto &t : th) t.join();
+    throw;
+  }
   for (auto &t : th) t.join();
   for (size_t s = 0; s < k; ++s)
     if (rc[s] != 0) {
@@ -123,7 +154,7 @@ void gather(const ShardedState *st, size_t s, const std::vector<uint32_t> &qs, c
 
 }  // namespace
 
-int sharded_create(ShardedState **out, const int *devices, int ndev) {
+static int create_impl(ShardedState **out, const int *devices, int ndev) {
   if (!devices || ndev < 1) {
     set_error("bivx_create_sharded: need at least one device");
     return BIVX_E_INVALID;
@@ -157,7 +188,7 @@ int sharded_device_of_chrom(const ShardedState *st, uint32_t chrom) {
   return st->devices[st->chrom_shard[chrom]];
 }
 
-int sharded_append(ShardedState *st, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
+static int append_impl(ShardedState *st, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
                    const uint8_t *svtype, size_t n) {
   if (n && (!low || !high)) {
     set_error("bivx_append: null argument");
@@ -182,7 +213,7 @@ int sharded_append(ShardedState *st, const uint32_t *chrom, const uint32_t *low,
   return 0;
 }
 
-int sharded_clear(ShardedState *st) {
+static int clear_impl(ShardedState *st) {
   st->chrom.clear();
   st->low.clear();
   st->high.clear();
@@ -198,18 +229,21 @@ bool sharded_is_built(const ShardedState *st) { return st->built && st->built_n 
 uint32_t sharded_num_chroms(const ShardedState *st) { return st->nchrom; }
 uint32_t sharded_num_types(const ShardedState *st) { return st->ntypes; }
 
-int sharded_build(ShardedState *st) {
+static int build_impl(ShardedState *st) {
   if (sharded_is_built(st)) return 0;
   const size_t n = st->low.size(), k = st->shard.size();
-  uint32_t nchrom = 0, max_type = 0;
+  uint32_t max_chrom = 0, max_type = 0;
   for (size_t i = 0; i < n; ++i) {
-    nchrom = std::max(nchrom, st->chrom[i] + 1);
+    max_chrom = std::max(max_chrom, st->chrom[i]);
     max_type = std::max<uint32_t>(max_type, st->type[i]);
   }
-  if (n && nchrom > BIVX_MAX_CHROMS) {
-    set_error("chromosome id %u exceeds BIVX_MAX_CHROMS", nchrom - 1);
+  // on the id itself, before anything is indexed by it (id + 1 wraps to 0 for 0xFFFFFFFF); the single-device build
+  // rejects the same input the same way (capi.hip, bivx_build)
+  if (n && max_chrom >= BIVX_MAX_CHROMS) {
+    set_error("chromosome id %u exceeds BIVX_MAX_CHROMS", max_chrom);
     return BIVX_E_RANGE;
   }
+  const uint32_t nchrom = n ? max_chrom + 1 : 0;
   std::vector<uint64_t> cnt(nchrom, 0);
   for (size_t i = 0; i < n; ++i) ++cnt[st->chrom[i]];
   const size_t populated = (size_t)std::count_if(cnt.begin(), cnt.end(), [](uint64_t c) { return c != 0; });
@@ -279,7 +313,7 @@ int sharded_get_svtypes(const ShardedState *st, const uint32_t *ids, size_t n, u
 }
 
 // the whole batch: every shard answers its queries (bivx_find_overlaps), the CSR is assembled in query order
-int sharded_find_overlaps(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+static int find_overlaps_impl(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                           size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
                           uint32_t **hit_ids_out) {
   *hit_ids_out = nullptr;
@@ -320,6 +354,10 @@ int sharded_find_overlaps(const ShardedState *st, const uint32_t *qchrom, const 
   }
   // Shard-local ids ascend with the global ones (a shard keeps append order), so a list that is ascending locally is
   // ascending globally: sort_by_id needs no second look.
+  struct FreeOnThrow {  // (thread creation below may throw)
+    uint32_t *p;
+    ~FreeOnThrow() { std::free(p); }
+  } guard{out};
   (void)on_every_shard(st, [&](size_t s) -> int {
     const uint32_t *g = st->by_chrom ? st->gid[s].data() : nullptr;
     for (size_t j = 0; j < r.qs[s].size(); ++j) {
@@ -331,11 +369,12 @@ int sharded_find_overlaps(const ShardedState *st, const uint32_t *qchrom, const 
     }
     return 0;
   });
+  guard.p = nullptr;
   *hit_ids_out = out;
   return 0;
 }
 
-int sharded_count(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+static int count_impl(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                   size_t q, const bivx_filter *filter, uint64_t *offsets_out) {
   if (!sharded_is_built(st)) {
     set_error("bivx_count: index not built (call bivx_build after the last append)");
@@ -361,13 +400,13 @@ int sharded_count(const ShardedState *st, const uint32_t *qchrom, const uint32_t
   return 0;
 }
 
-int sharded_fill(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+static int fill_impl(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                  size_t q, const bivx_filter *filter, const uint64_t *offsets, uint32_t *hit_ids_out,
                  int sort_by_id) {
   // the offsets are the caller's; the ids are what bivx_find_overlaps gives for the same batch
   std::vector<uint64_t> off(q + 1);
   uint32_t *hits = nullptr;
-  BIVX_TRY(sharded_find_overlaps(st, qchrom, qlow, qhigh, q, filter, sort_by_id, off.data(), &hits));
+  BIVX_TRY(find_overlaps_impl(st, qchrom, qlow, qhigh, q, filter, sort_by_id, off.data(), &hits));
   int rc = 0;
   if (std::memcmp(off.data(), offsets, (q + 1) * sizeof(uint64_t)) != 0) {
     set_error("bivx_fill: offsets do not belong to this batch");
@@ -379,7 +418,7 @@ int sharded_fill(const ShardedState *st, const uint32_t *qchrom, const uint32_t 
   return rc;
 }
 
-int sharded_any(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+static int any_impl(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                 size_t q, uint32_t *first_id_out) {
   if (!sharded_is_built(st)) {
     set_error("bivx_any: index not built (call bivx_build after the last append)");
@@ -416,6 +455,55 @@ void sharded_stats(const ShardedState *st, bivx_stats *out) {
     out->staging_bytes += s.staging_bytes;
     out->prefix_timeouts += s.prefix_timeouts;
   }
+}
+
+
+// ---- the entry points capi.hip dispatches to: the implementations above behind the exception barrier ----------------
+int sharded_create(ShardedState **out, const int *devices, int ndev) {
+  return no_throw("bivx_create_sharded", [&] { return create_impl(out, devices, ndev); });
+}
+int sharded_append(ShardedState *st, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
+                   const uint8_t *svtype, size_t n) {
+  const size_t old = st->low.size();
+  const int rc = no_throw("bivx_append", [&] { return append_impl(st, chrom, low, high, svtype, n); });
+  if (rc != 0) {  // an append that ran out of memory half-way leaves the four columns at their old, equal length
+    try {
+      st->low.resize(std::min(st->low.size(), old));
+      st->high.resize(std::min(st->high.size(), old));
+      st->chrom.resize(std::min(st->chrom.size(), old));
+      st->type.resize(std::min(st->type.size(), old));
+    } catch (...) {
+    }
+  }
+  return rc;
+}
+int sharded_clear(ShardedState *st) {
+  return no_throw("bivx_clear", [&] { return clear_impl(st); });
+}
+int sharded_build(ShardedState *st) {
+  return no_throw("bivx_build", [&] { return build_impl(st); });
+}
+int sharded_find_overlaps(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                          size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+                          uint32_t **hit_ids_out) {
+  return no_throw("bivx_find_overlaps", [&] {
+    return find_overlaps_impl(st, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
+  });
+}
+int sharded_count(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                  size_t q, const bivx_filter *filter, uint64_t *offsets_out) {
+  return no_throw("bivx_count", [&] { return count_impl(st, qchrom, qlow, qhigh, q, filter, offsets_out); });
+}
+int sharded_fill(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                 size_t q, const bivx_filter *filter, const uint64_t *offsets, uint32_t *hit_ids_out,
+                 int sort_by_id) {
+  return no_throw("bivx_fill", [&] {
+    return fill_impl(st, qchrom, qlow, qhigh, q, filter, offsets, hit_ids_out, sort_by_id);
+  });
+}
+int sharded_any(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                size_t q, uint32_t *first_id_out) {
+  return no_throw("bivx_any", [&] { return any_impl(st, qchrom, qlow, qhigh, q, first_id_out); });
 }
 
 }  // namespace bivx

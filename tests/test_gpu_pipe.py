@@ -402,7 +402,8 @@ def test_every_slice_of_a_large_batch_listed():
         off = idx.count_overlaps_device(d_qlo, d_qhi)
         H = int(off[-1].item())
         assert 5.2 * qlo.size < H <= 6 * qlo.size
-        assert idx.query_kernel_name(qlo.size, H) == "k_query_pipe"
+        if os.environ.get("BIVX_PIPE", "1") != "0":   # (a suite run with the pipelined kernels switched off)
+            assert idx.query_kernel_name(qlo.size, H) == "k_query_pipe"
         res = []
         for mode in (1, 0):
             with _env(BIVX_PIPE=mode):

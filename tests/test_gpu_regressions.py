@@ -1,0 +1,146 @@
+"""Regression tests for the advisor's round-2 findings — each one failed, or was not pinned, before its fix.
+
+  * stale svtype bytes surviving bivx_clear (capi.hip): typed append, clear, untyped append, typed append, build, query by type
+  * chromosome id 0xFFFFFFFF in the sharded build (sharded.cpp): BIVX_E_RANGE, as on one device, no out-of-bounds write
+  * k_query_tiny / the mailbox path (query.hip, capi.hip find_overlaps_tiny, bivx_any with q <= 64): q in 2..65 on a typed,
+    multi-class, multi-chromosome index with a pile-up point (wavefront-cooperative windows in the fill enumeration),
+    totals exactly at and just above the mailbox's 7870-id capacity, and the fallback chain tiny -> small -> count/fill
+All against the brute-force closed-interval predicate (interval_tree.hpp:119-121)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _brute(chrom, low, high, sel, qc, qlo, qhi):
+    """per query: ascending ids of the selected intervals that overlap it on its chromosome"""
+    out = []
+    ids = np.arange(low.size)
+    for c, lo, hi in zip(qc, qlo, qhi):
+        m = sel & (chrom == c) & (low <= hi) & (high >= lo)
+        out.append(ids[m])
+    return out
+
+
+def _check_csr(off, hits, expected, ordered):
+    assert off[0] == 0 and off[-1] == sum(e.size for e in expected)
+    for k, e in enumerate(expected):
+        g = hits[int(off[k]):int(off[k + 1])].astype(np.int64)
+        if ordered:
+            assert np.array_equal(g, e), k
+        else:
+            assert np.array_equal(np.sort(g), e), k
+
+
+def test_clear_does_not_leave_svtype_bytes_behind():
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(5)
+    n = 5000
+    low = rng.integers(0, 100_000, n).astype(np.uint32)
+    high = (low + rng.integers(0, 500, n)).astype(np.uint32)
+    qlo = rng.integers(0, 100_000, 300).astype(np.uint32)
+    qhi = (qlo + 400).astype(np.uint32)
+    z = np.zeros(qlo.size, np.uint32)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high, svtype=np.full(n, 2, np.uint8))     # every slot labelled 2
+        idx.build()
+        idx.clear()
+        half = n // 2
+        idx.insert_node(low[:half], high[:half])                       # untyped: reuses the first slots
+        idx.insert_node(low[half:], high[half:], svtype=np.full(n - half, 3, np.uint8))
+        idx.build()
+        typ = np.r_[np.zeros(half, np.uint8), np.full(n - half, 3, np.uint8)]
+        assert np.array_equal(idx.get_svtypes(np.arange(n, dtype=np.uint32)), typ)
+        chrom = np.zeros(n, np.uint32)
+        for t in (0, 2, 3):
+            sel = np.ones(n, bool) if t == 0 else typ == t
+            off, hits = idx.find_overlaps(qlo, qhi, svtype=t)
+            _check_csr(off, hits, _brute(chrom, low, high, sel, z, qlo, qhi), True)
+
+
+def test_sharded_build_rejects_chromosome_id_beyond_the_limit():
+    from binary_amd import IntervalIndex, capi
+    low = np.array([10, 20, 30], np.uint32)
+    high = low + 5
+    for bad in (0xFFFFFFFF, 65536):
+        with IntervalIndex([0, 0]) as idx:
+            idx.insert_node(low, high, np.array([0, bad, 1], np.uint32))
+            with pytest.raises(capi.BivxError) as e:
+                idx.build()
+            assert e.value.code == capi.E_RANGE
+        with IntervalIndex(0) as idx:                                   # the single-device build says the same
+            idx.insert_node(low, high, np.array([0, bad, 1], np.uint32))
+            with pytest.raises(capi.BivxError) as e:
+                idx.build()
+            assert e.value.code == capi.E_RANGE
+    with IntervalIndex([0, 0]) as idx:                                  # the largest id that is allowed
+        idx.insert_node(low, high, np.array([0, 65535, 1], np.uint32))
+        idx.build()
+        off, hits = idx.find_overlaps(np.array([20], np.uint32), np.array([22], np.uint32), np.array([65535], np.uint32))
+        assert off.tolist() == [0, 1] and hits.tolist() == [1]
+
+
+def _typed_multiclass_index(seed):
+    """3 chromosomes, types 1..3, short and long intervals (several length classes per partition), and on chromosome 1 a
+    pile-up: 3000 intervals that all contain coordinate 500_000 (windows of far more than 64 slots)."""
+    rng = np.random.default_rng(seed)
+    n = 40_000
+    chrom = rng.integers(0, 3, n).astype(np.uint32)
+    low = rng.integers(0, 1_000_000, n).astype(np.uint32)
+    ln = rng.integers(0, 600, n)
+    ln[::40] = rng.integers(20_000, 300_000, ln[::40].size)
+    high = (low + ln).astype(np.uint32)
+    typ = rng.integers(1, 4, n).astype(np.uint8)
+    pile = slice(1000, 4000)
+    chrom[pile] = 1
+    low[pile] = 500_000 - rng.integers(0, 50, 3000)
+    high[pile] = 500_000 + rng.integers(0, 50, 3000)
+    return chrom, low, high, typ
+
+
+@pytest.mark.parametrize("q", [2, 3, 17, 63, 64, 65])
+@pytest.mark.parametrize("ordered", [True, False])
+def test_few_queries_host_calls_typed_multiclass(q, ordered):
+    from binary_amd import IntervalIndex, capi
+    chrom, low, high, typ = _typed_multiclass_index(100 + q)
+    rng = np.random.default_rng(q)
+    qc = rng.integers(0, 4, q).astype(np.uint32)            # chromosome 3 is unknown to the index
+    qlo = rng.integers(0, 1_000_000, q).astype(np.uint32)
+    qhi = (qlo + rng.integers(0, 3000, q)).astype(np.uint32)
+    qc[0], qlo[0], qhi[0] = 1, 499_990, 500_010            # the pile-up: a wavefront-cooperative window
+    if q > 2:
+        qc[2], qlo[2], qhi[2] = 0, 0, 0xFFFFFFFF           # a chromosome-wide query
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high, chrom, svtype=typ)
+        idx.build()
+        assert idx.stats()["n_segments"] > 9               # several length classes per (chromosome, type)
+        for t in (0, 1, 3):
+            sel = np.ones(low.size, bool) if t == 0 else typ == t
+            exp = _brute(chrom, low, high, sel, qc, qlo, qhi)
+            off, hits = idx.find_overlaps(qlo, qhi, qc, sort_by_id=ordered, svtype=t)
+            _check_csr(off, hits, exp, ordered)
+        first = idx.find_overlap(qlo, qhi, qc)             # bivx_any: through the mailbox up to 64 queries
+        exp = _brute(chrom, low, high, np.ones(low.size, bool), qc, qlo, qhi)
+        want = np.array([e[0] if e.size else capi.BIVX_NO_HIT for e in exp], np.uint32)
+        assert np.array_equal(first, want)
+
+
+@pytest.mark.parametrize("extra", [0, 1])
+def test_mailbox_capacity_edge_and_fallback(extra):
+    """10 queries x 787 hits = 7870 ids fill the mailbox exactly; one more id overflows it and the call falls back to
+    the copying single pass (whose buffer holds 32 ids per query + 1024: overflows too) and then to count + fill."""
+    from binary_amd import IntervalIndex
+    K = 787
+    low = np.r_[np.full(K, 1000), [5000]].astype(np.uint32)
+    high = (low + 10).astype(np.uint32)
+    chrom = np.full(K + 1, 2, np.uint32)
+    q = 10 + extra
+    qlo = np.r_[np.full(10, 1005), [5005] * extra].astype(np.uint32)
+    qc = np.full(q, 2, np.uint32)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high, chrom)
+        idx.build()
+        for ordered in (True, False):
+            off, hits = idx.find_overlaps(qlo, qlo, qc, sort_by_id=ordered)
+            assert int(off[-1]) == 7870 + extra
+            _check_csr(off, hits, _brute(chrom, low, high, np.ones(K + 1, bool), qc, qlo, qlo), ordered)

@@ -53,14 +53,22 @@ def _rank_csr(oracle_mod, data, chroms):
             np.concatenate(ids_global) if ids_global else np.zeros(0, np.int64))
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, self_overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import ivtree_oracle as oracle_mod
-        data = synth.gen_genome(6000, 4000, 1000)
-        assign = sharding.lpt_assign(sharding.chrom_work(synth.split_by_length(6000), synth.split_by_length(4000)), world)
+        if self_overlap:
+            # BASELINE config 5 in miniature, as bench.py --config 5 shards it under WORLD_SIZE > 1: queries = the
+            # intervals, chromosome sizes skewed (proportional to length), LPT on Q_c log2 N_c + E[H_c]
+            data = synth.gen_genome(9000, 0, 1000)
+            data["qchrom"], data["qlow"], data["qhigh"] = data["chrom"], data["low"], data["high"]
+            ni = synth.split_by_length(9000)
+            assign = sharding.lpt_assign(sharding.chrom_work(ni, ni, ni * ni * 1002.0 / synth.HG38_LENGTHS), world)
+        else:
+            data = synth.gen_genome(6000, 4000, 1000)
+            assign = sharding.lpt_assign(sharding.chrom_work(synth.split_by_length(6000), synth.split_by_length(4000)), world)
         off, hits, qids = _rank_csr(oracle_mod, data, assign[rank])
         res = sharding.gatherv_csr(torch.from_numpy(off), torch.from_numpy(hits), dst=0)
         if rank == 0:
@@ -91,6 +99,12 @@ def _worker(rank, world, port, tmpdir):
 def test_gatherv_csr_gloo(world, tmp_path, oracle):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_gatherv_csr_gloo_self_overlap_skewed(tmp_path, oracle):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
 
 
