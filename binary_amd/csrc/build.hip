@@ -6,6 +6,7 @@
 // radix sort of (segment, low) carrying the append-order id -> gather (low, high) -> bucket directory.
 // All integer/byte work; bound by HBM streaming and scatter, never by MFMA.
 #include "common.h"
+#include "wave_device.h"
 
 namespace bivx {
 namespace {
@@ -18,37 +19,67 @@ __device__ __forceinline__ uint32_t len_bin(uint32_t low, uint32_t high, uint32_
 }
 
 // ---- per (chromosome, length bin) statistics ---------------------------------------------------------
+// One pass over the appended columns. A wavefront takes 64 intervals at a time and aggregates them by (partition,
+// length bin) BEFORE anything touches a shared table: for every distinct key among its 64 lanes (a scalar loop over
+// ballots) the count is a popcount and min / max are DPP reductions, and one lane adds the result to the table. The
+// first form did five LDS atomics per interval, all of a workgroup's lanes on the ~10 words of one chromosome's common
+// length bins: the LDS serialises same-address atomics, so 10 M intervals took 169 us — 0.7 TB/s for a 120 MB read.
 
-constexpr uint32_t kStatsLdsEntries = 1650;  // (chrom, bin) pairs privatised in LDS (50 chromosomes, 33 KB)
+constexpr uint32_t kStatsLdsEntries = 3300;  // (partition, bin) pairs privatised in LDS (100 partitions: 66 KB)
+constexpr int kStatsThreads = 512;
+
+// the partition ("virtual chromosome") of interval i: chrom * ntypes + svtype (include/bivx.h, bivx_append_typed)
+__device__ __forceinline__ uint32_t part_of(const uint32_t *__restrict__ chrom, const uint8_t *__restrict__ type,
+                                            uint32_t ntypes, size_t i) {
+  const uint32_t c = chrom ? chrom[i] : 0u;
+  return type ? c * ntypes + type[i] : c;
+}
 
 template <bool USE_LDS>
-__global__ __launch_bounds__(kThreads) void k_bin_stats(const uint32_t *__restrict__ chrom,
-                                                        const uint32_t *__restrict__ low,
-                                                        const uint32_t *__restrict__ high, size_t n,
-                                                        uint32_t nchrom, BinStats *__restrict__ stats) {
+__global__ __launch_bounds__(kStatsThreads) void k_bin_stats(const uint32_t *__restrict__ chrom,
+                                                             const uint8_t *__restrict__ type, uint32_t ntypes,
+                                                             const uint32_t *__restrict__ low,
+                                                             const uint32_t *__restrict__ high, size_t n,
+                                                             uint32_t nent, BinStats *__restrict__ stats) {
   __shared__ BinStats lds[USE_LDS ? kStatsLdsEntries : 1];
-  const uint32_t nent = nchrom * kLenBins;
   if (USE_LDS) {
-    for (uint32_t e = threadIdx.x; e < nent; e += kThreads) lds[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u, 0u};
+    for (uint32_t e = threadIdx.x; e < nent; e += kStatsThreads) lds[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u, 0u};
     __syncthreads();
   }
   BinStats *tab = USE_LDS ? lds : stats;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
-    const uint32_t c = chrom ? chrom[i] : 0u;
-    const uint32_t lo = low[i];
-    const uint32_t hi = high[i];
-    uint32_t len;
-    const uint32_t b = len_bin(lo, hi, len);
-    BinStats *e = tab + (size_t)c * kLenBins + b;
-    atomicAdd(&e->count, 1u);
-    if (lo > hi) atomicAdd(&e->n_inverted, 1u);
-    atomicMin(&e->min_low, lo);
-    atomicMax(&e->max_low, lo);
-    atomicMax(&e->max_len, len);
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  // (wavefront-uniform trip count: the reductions below need all 64 lanes)
+  for (size_t i0 = ((size_t)blockIdx.x * kStatsThreads + (threadIdx.x & ~(uint32_t)(kWave - 1))); i0 < n;
+       i0 += (size_t)gridDim.x * kStatsThreads) {
+    const size_t i = i0 + lane;
+    const bool valid = i < n;
+    uint32_t lo = 0, hi = 0, key = 0xFFFFFFFFu, len = 0;
+    if (valid) {
+      lo = low[i];
+      hi = high[i];
+      key = part_of(chrom, type, ntypes, i) * kLenBins + len_bin(lo, hi, len);
+    }
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+      const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)todo) - 1);
+      const bool in = key == k;
+      const uint64_t m = __ballot(in);
+      const uint32_t mn = wave_min(in ? lo : 0xFFFFFFFFu), mx = wave_max(in ? lo : 0u), ml = wave_max(in ? len : 0u);
+      const uint32_t ninv = (uint32_t)__popcll(__ballot(in && lo > hi));
+      if (lane == 0) {
+        BinStats *e = tab + k;
+        atomicAdd(&e->count, (uint32_t)__popcll(m));
+        atomicMin(&e->min_low, mn);
+        atomicMax(&e->max_low, mx);
+        atomicMax(&e->max_len, ml);
+        if (ninv) atomicAdd(&e->n_inverted, ninv);
+      }
+      todo &= ~m;
+    }
   }
   if (USE_LDS) {
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < nent; e += kThreads) {
+    for (uint32_t e = threadIdx.x; e < nent; e += kStatsThreads) {
       const BinStats s = lds[e];
       if (s.count) {
         atomicAdd(&stats[e].count, s.count);
@@ -66,14 +97,48 @@ __global__ __launch_bounds__(kThreads) void k_init_stats(BinStats *stats, uint32
   if (e < nent) stats[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u, 0u};
 }
 
-__global__ __launch_bounds__(kThreads) void k_max_u32(const uint32_t *__restrict__ in, size_t n,
-                                                      uint32_t *__restrict__ out) {
-  uint32_t m = 0;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
-    m = max(m, in[i]);
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, kWave));
-  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
+// workgroup maximum of one value per thread -> ONE atomic per workgroup (every wavefront of a 2 048-workgroup grid
+// adding to one address, as the first form did, is 8 192 same-address device atomics of ~10 ns each: 100 us to reduce
+// 40 MB)
+__device__ __forceinline__ void block_max_to(uint32_t m, uint32_t *out) {
+  __shared__ uint32_t s_m[kThreads / kWave];
+  m = wave_max(m);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t r = 0;
+    for (int w = 0; w < kThreads / kWave; ++w) r = max(r, s_m[w]);
+    if (r) atomicMax(out, r);
+  }
+}
+
+// out[0] = max chromosome id, out[1] = max svtype (type may be nullptr), in one pass
+__global__ __launch_bounds__(kThreads) void k_max_chrom_type(const uint32_t *__restrict__ chrom,
+                                                             const uint8_t *__restrict__ type, size_t n,
+                                                             uint32_t *__restrict__ out) {
+  uint32_t mc = 0, mt = 0;
+  const size_t n4 = n / 4;
+  const uint4 *c4 = reinterpret_cast<const uint4 *>(chrom);
+  const uint32_t *t4 = reinterpret_cast<const uint32_t *>(type);
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (size_t)gridDim.x * kThreads) {
+    if (chrom) {
+      const uint4 v = c4[i];
+      mc = max(max(mc, v.x), max(max(v.y, v.z), v.w));
+    }
+    if (type) {
+      const uint32_t t = t4[i];
+      mt = max(max(mt, t & 0xFFu), max(max((t >> 8) & 0xFFu, (t >> 16) & 0xFFu), t >> 24));
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    if (chrom) mc = max(mc, chrom[i]);
+    if (type) mt = max(mt, (uint32_t)type[i]);
+  }
+  // (both reductions by every thread: block_max_to holds a barrier)
+  block_max_to(mc, out);
+  __syncthreads();
+  block_max_to(mt, out + 1);
 }
 
 // largest number of slots any directory cell holds: max over e of table[e + 1] - table[e] (a segment's entries end with
@@ -85,27 +150,7 @@ __global__ __launch_bounds__(kThreads) void k_max_cell(const uint32_t *__restric
     const uint32_t a = table[i], b = table[i + 1];
     m = max(m, b > a ? b - a : 0u);
   }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, kWave));
-  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
-}
-
-__global__ __launch_bounds__(kThreads) void k_max_u8(const uint8_t *__restrict__ in, size_t n,
-                                                     uint32_t *__restrict__ out) {
-  uint32_t m = 0;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
-    m = max(m, (uint32_t)in[i]);
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, kWave));
-  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
-}
-
-// the (chromosome, svtype) partition id of every interval (include/bivx.h, bivx_append_typed)
-__global__ __launch_bounds__(kThreads) void k_make_vchrom(const uint32_t *__restrict__ chrom,
-                                                          const uint8_t *__restrict__ type, size_t n,
-                                                          uint32_t ntypes, uint32_t *__restrict__ vchrom) {
-  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) vchrom[i] = (chrom ? chrom[i] : 0u) * ntypes + type[i];
+  block_max_to(m, out);
 }
 
 __global__ __launch_bounds__(kThreads) void k_gather_u8(const uint8_t *__restrict__ src,
@@ -116,33 +161,58 @@ __global__ __launch_bounds__(kThreads) void k_gather_u8(const uint8_t *__restric
 }
 
 // ---- sort keys -----------------------------------------------------------------------------------------
+// The order the index wants is (segment, low, id). ONE 32-bit key gives it whenever the segments' coordinate spans add
+// up to less than 2^32 (24 human chromosomes: 3.09 G): segment s owns the key range [keybase[s], keybase[s] + span_s]
+// and an interval's key is keybase[seg] + (low - base[seg]) — a stable sort by that key is the whole job, and `low`
+// comes back out of the sorted key (no gather). Otherwise (kKeyLow / kKeySegOfId) two stable sorts: by low, then by
+// segment of the ids as they lie after the first.
+enum : int { kKeyDense = 0, kKeyLow = 1, kKeySegOfId = 2 };
 
-__global__ __launch_bounds__(kThreads) void k_make_segkeys(const uint32_t *__restrict__ chrom,
-                                                           const uint32_t *__restrict__ low,
-                                                           const uint32_t *__restrict__ high, size_t n,
-                                                           const uint32_t *__restrict__ bin2seg,
-                                                           uint32_t *__restrict__ segkey,
-                                                           uint32_t *__restrict__ ids) {
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_make_keys(const uint32_t *__restrict__ chrom,
+                                                        const uint8_t *__restrict__ type, uint32_t ntypes,
+                                                        const uint32_t *__restrict__ low,
+                                                        const uint32_t *__restrict__ high, size_t n,
+                                                        const uint32_t *__restrict__ bin2seg,
+                                                        const uint2 *__restrict__ segkey,  // (keybase, base) per segment
+                                                        const uint32_t *__restrict__ ids,   // kKeySegOfId: sorted ids
+                                                        uint32_t *__restrict__ keys) {
   const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
-  const uint32_t c = chrom ? chrom[i] : 0u;
+  if (MODE == kKeyLow) {
+    keys[i] = low[i];
+    return;
+  }
+  const size_t j = MODE == kKeySegOfId ? ids[i] : i;
   uint32_t len;
-  const uint32_t b = len_bin(low[i], high[i], len);
-  segkey[i] = bin2seg[(size_t)c * kLenBins + b];
-  ids[i] = (uint32_t)i;
+  const uint32_t lo = low[j];
+  const uint32_t b = len_bin(lo, high[j], len);
+  const uint32_t seg = bin2seg[(size_t)part_of(chrom, type, ntypes, j) * kLenBins + b];
+  if (MODE == kKeySegOfId) {
+    keys[i] = seg;
+  } else {
+    const uint2 k = segkey[seg];
+    keys[i] = k.x + (lo - k.y);
+  }
 }
 
 // ---- stable LSD radix sort, 8 bits per pass --------------------------------------------------------------
 //
-// A workgroup owns a tile of kTile consecutive keys; wave w owns the w-th quarter of the tile and lane l
-// of round r the key at quarter + r*64 + l, so "position in tile" order is (wave, round, lane). Ranks
-// inside a round come from a ballot match on the 8 digit bits, which needs no LDS atomics and is stable.
+// A workgroup (512 threads) owns a tile of 8 192 consecutive keys; wave w owns the w-th eighth of the tile and lane l
+// of round r the key at eighth + r * 64 + l, so "position in tile" order is (wave, round, lane). Ranks inside a round
+// come from a ballot match on the 8 digit bits, which needs no LDS atomics and is stable. The tile is then REORDERED
+// by digit in LDS and leaves in that order: with 256 digits and 8 192 keys a digit's keys of one tile are ~32
+// neighbours in the output, i.e. whole 128-byte lines per store instruction. (The first form scattered straight from
+// registers, 1 024 keys per tile: 4-key fragments, every line of the output written in sixteen pieces — 121 us per
+// pass for 160 MB.)
 
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
-constexpr int kRounds = 4;
-constexpr int kWaves = kThreads / kWave;
-constexpr int kTile = kThreads * kRounds;  // 1024 keys (more rounds per thread cost ~20 VGPRs each: 16 took 256)
+constexpr int kSortThreads = 512;
+constexpr int kSortWaves = kSortThreads / kWave;       // 8
+constexpr int kSortRounds = 16;                        // keys per thread
+constexpr int kTile = kSortThreads * kSortRounds;      // 8 192 keys
+constexpr int kWaveKeys = kTile / kSortWaves;          // 1 024
 
 __device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid) {
   uint64_t m = __ballot(valid);
@@ -156,97 +226,117 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid) {
 }
 
 // hist[digit * nblocks + block] = number of keys with that digit in that tile
-__global__ __launch_bounds__(kThreads) void k_radix_hist(const uint32_t *__restrict__ keys, size_t n, int shift,
-                                                         uint32_t *__restrict__ hist, uint32_t nblocks) {
-  __shared__ uint32_t cnt[kRadix];
-  cnt[threadIdx.x] = 0;
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ keys, size_t n, int shift,
+                                                             uint32_t *__restrict__ hist, uint32_t nblocks) {
+  __shared__ uint32_t cnt[kSortWaves][kRadix];  // one table per wavefront: waves do not contend with each other
+  for (int w = 0; w < kSortWaves; ++w)
+    if (threadIdx.x < kRadix) cnt[w][threadIdx.x] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * kTile;
+  uint32_t *mine = cnt[threadIdx.x >> 6];
 #pragma unroll 4
-  for (int r = 0; r < kRounds; ++r) {
-    const size_t i = base + (size_t)r * kThreads + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & (kRadix - 1)], 1u);
+  for (int r = 0; r < kSortRounds; ++r) {
+    const size_t i = base + (size_t)r * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&mine[(keys[i] >> shift) & (kRadix - 1)], 1u);
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = cnt[threadIdx.x];
+  if (threadIdx.x < kRadix) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) c += cnt[w][threadIdx.x];
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = c;
+  }
 }
 
-__global__ __launch_bounds__(kThreads) void k_radix_scatter(const uint32_t *__restrict__ keys_in,
-                                                            const uint32_t *__restrict__ vals_in,
-                                                            uint32_t *__restrict__ keys_out,
-                                                            uint32_t *__restrict__ vals_out, size_t n, int shift,
-                                                            const uint32_t *__restrict__ offs, uint32_t nblocks) {
-  __shared__ uint32_t wcnt[kWaves][kRadix];  // per-wave digit counts, then per-wave running bases
+// IOTA: the values are the keys' own indices (first pass of a sort whose values are the ids 0 .. n-1): nothing is read.
+template <bool IOTA>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ keys_in,
+                                                                const uint32_t *__restrict__ vals_in,
+                                                                uint32_t *__restrict__ keys_out,
+                                                                uint32_t *__restrict__ vals_out, size_t n, int shift,
+                                                                const uint32_t *__restrict__ offs, uint32_t nblocks) {
+  __shared__ uint32_t s_key[kTile];
+  __shared__ uint32_t s_val[kTile];
+  __shared__ uint32_t wcnt[kSortWaves][kRadix];  // per-wave digit counts, then the waves' first positions per digit
+  __shared__ uint32_t s_goff[kRadix];            // where tile position j of digit d goes: s_goff[d] + j
+  __shared__ uint32_t s_wsum[kSortWaves];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  for (int w = 0; w < kWaves; ++w) wcnt[w][threadIdx.x] = 0;
+  for (int w = 0; w < kSortWaves; ++w)
+    if (threadIdx.x < kRadix) wcnt[w][threadIdx.x] = 0;
   __syncthreads();
 
-  const size_t wbase = (size_t)blockIdx.x * kTile + (size_t)wave * (kTile / kWaves);
-  uint32_t key[kRounds], val[kRounds];
-  volatile uint32_t *mycnt = wcnt[wave];
-  // phase A: load the wave's quarter, count digits (one leader lane per distinct digit adds the group size)
+  const size_t tbase = (size_t)blockIdx.x * kTile;
+  const size_t wbase = tbase + (size_t)wave * kWaveKeys;
+  uint32_t key[kSortRounds], val[kSortRounds];
+  uint32_t rank[kSortRounds / 2];  // two 16-bit ranks per register: rank of the key among its wave's keys of that digit
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
+  for (int r = 0; r < kSortRounds; ++r) {
     const size_t i = wbase + (size_t)r * kWave + lane;
-    const bool valid = i < n;
-    key[r] = valid ? keys_in[i] : 0u;
-    val[r] = valid ? vals_in[i] : 0u;
-    const uint32_t dg = (key[r] >> shift) & (kRadix - 1);
-    const uint64_t m = match_digit(dg, valid);
-    if (valid && (m & ((1ull << lane) - 1ull)) == 0) mycnt[dg] += (uint32_t)__popcll(m);
-    __builtin_amdgcn_wave_barrier();
+    key[r] = i < n ? keys_in[i] : 0u;
+    val[r] = IOTA ? (uint32_t)i : (i < n ? vals_in[i] : 0u);
   }
-  __syncthreads();
-  // thread t = digit t: turn per-wave counts into per-wave global bases
-  {
-    uint32_t run = offs[(size_t)threadIdx.x * nblocks + blockIdx.x];
-    for (int w = 0; w < kWaves; ++w) {
-      const uint32_t c = wcnt[w][threadIdx.x];
-      wcnt[w][threadIdx.x] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-  // phase B: replay the rounds in the same order; base[digit] advances by the group size each round
+  volatile uint32_t *mycnt = wcnt[wave];  // (other lanes of the wavefront write what this lane reads a round later)
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
+  for (int r = 0; r < kSortRounds; ++r) {
     const size_t i = wbase + (size_t)r * kWave + lane;
     const bool valid = i < n;
     const uint32_t dg = (key[r] >> shift) & (kRadix - 1);
     const uint64_t m = match_digit(dg, valid);
     const uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    uint32_t pos = 0;
-    if (valid) pos = mycnt[dg] + below;
+    const uint32_t before = valid ? mycnt[dg] : 0u;  // (a wavefront's LDS operations execute in order)
     __builtin_amdgcn_wave_barrier();
-    if (valid && below == 0) mycnt[dg] += (uint32_t)__popcll(m);
+    if (valid && below == 0) mycnt[dg] = before + (uint32_t)__popcll(m);  // the group's first lane
     __builtin_amdgcn_wave_barrier();
-    if (valid) {
-      keys_out[pos] = key[r];
-      vals_out[pos] = val[r];
+    const uint32_t rk = before + below;
+    if (r & 1) rank[r >> 1] |= rk << 16;
+    else rank[r >> 1] = rk;
+  }
+  __syncthreads();
+  // thread t = digit t: the waves' counts become the waves' first positions inside the digit's run; the digits' runs
+  // are laid out one after the other in the tile (an exclusive scan over the 256 digit totals)
+  uint32_t total = 0;
+  if (threadIdx.x < kRadix) {
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+      const uint32_t c = wcnt[w][threadIdx.x];
+      wcnt[w][threadIdx.x] = total;
+      total += c;
     }
+  }
+  const uint32_t incl = wave_scan_incl(total);
+  if (lane == kWave - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x < kRadix) {
+    uint32_t excl = incl - total;
+    for (int w = 0; w < wave; ++w) excl += s_wsum[w];
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) wcnt[w][threadIdx.x] += excl;
+    s_goff[threadIdx.x] = offs[(size_t)threadIdx.x * nblocks + blockIdx.x] - excl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r) {
+    const size_t i = wbase + (size_t)r * kWave + lane;
+    if (i < n) {
+      const uint32_t dg = (key[r] >> shift) & (kRadix - 1);
+      const uint32_t pos = mycnt[dg] + ((rank[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu);
+      s_key[pos] = key[r];
+      s_val[pos] = val[r];
+    }
+  }
+  __syncthreads();
+  const uint32_t count = n - tbase < (size_t)kTile ? (uint32_t)(n - tbase) : (uint32_t)kTile;
+#pragma unroll 4
+  for (uint32_t j = threadIdx.x; j < count; j += kSortThreads) {
+    const uint32_t k = s_key[j];
+    const uint32_t out = s_goff[(k >> shift) & (kRadix - 1)] + j;
+    keys_out[out] = k;
+    vals_out[out] = s_val[j];
   }
 }
 
 // ---- gathers ---------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(kThreads) void k_gather_u32(const uint32_t *__restrict__ src,
-                                                         const uint32_t *__restrict__ idx,
-                                                         uint32_t *__restrict__ dst, size_t n) {
-  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
-}
-
-__global__ __launch_bounds__(kThreads) void k_gather_se(const uint32_t *__restrict__ low,
-                                                        const uint32_t *__restrict__ high,
-                                                        const uint32_t *__restrict__ idx, uint2 *__restrict__ se,
-                                                        size_t n) {
-  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) {
-    const uint32_t j = idx[i];
-    se[i] = make_uint2(low[j], high[j]);
-  }
-}
 
 __global__ __launch_bounds__(kThreads) void k_gather_intervals(const uint32_t *__restrict__ chrom,
                                                                const uint32_t *__restrict__ low,
@@ -262,6 +352,46 @@ __global__ __launch_bounds__(kThreads) void k_gather_intervals(const uint32_t *_
   if (oc) oc[i] = ok ? (chrom ? chrom[j] : 0u) : 0xFFFFFFFFu;
   if (ol) ol[i] = ok ? low[j] : 0xFFFFFFFFu;
   if (oh) oh[i] = ok ? high[j] : 0u;
+}
+
+// ---- the sorted arrays -------------------------------------------------------------------------------------
+// se[i] = (low, high) of sorted slot i, rec[i] = its packed record beside its id (kSegPacked segments; (0, id) elsewhere),
+// from the sorted keys and ids in one pass. DENSE: low comes back out of the key (keybase / base of the slot's segment);
+// `high` is the one gather — by id, i.e. in append order, and ids of neighbouring slots are scattered over their
+// chromosome's part of the column. The launch is XCD-aware for it: workgroup b works on chunk (b % 8) * nchunks / 8 + b / 8,
+// so each of the eight L2s (workgroups are dealt round-robin over the XCDs) walks ONE contiguous eighth of the slots and
+// with it one chromosome's 3 MB of `high` at a time, instead of all eight walking all of it.
+template <bool DENSE>
+__global__ __launch_bounds__(kThreads) void k_finalize(const uint32_t *__restrict__ keys,
+                                                       const uint32_t *__restrict__ ids,
+                                                       const uint32_t *__restrict__ low,
+                                                       const uint32_t *__restrict__ high,
+                                                       const SegDesc *__restrict__ seg,
+                                                       const uint2 *__restrict__ segkey, uint32_t nseg,
+                                                       uint2 *__restrict__ se, uint2 *__restrict__ rec, size_t n,
+                                                       uint32_t nchunks) {
+  const uint32_t per = (nchunks + 7u) / 8u;
+  const uint32_t chunk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per || chunk >= nchunks) return;
+  const size_t i = (size_t)chunk * kThreads + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = nseg;  // last segment with begin <= i
+  while (hi - lo > 1) {
+    const uint32_t m = (lo + hi) >> 1;
+    if ((size_t)seg[m].begin <= i) lo = m; else hi = m;
+  }
+  const uint32_t shift = seg[lo].shift;
+  const uint32_t id = ids[i];
+  uint32_t l;
+  if (DENSE) {
+    const uint2 k = segkey[lo];
+    l = k.y + (keys[i] - k.x);
+  } else {
+    l = low[id];
+  }
+  const uint32_t h = high[id];
+  se[i] = make_uint2(l, h);
+  rec[i] = make_uint2((shift & kSegPacked) ? ((l & 0xFFFFu) | ((h - l) << 16)) : 0u, id);
 }
 
 // ---- bucket directory --------------------------------------------------------------------------------------
@@ -294,28 +424,6 @@ __global__ __launch_bounds__(kThreads) void k_build_table(const uint2 *__restric
   table[e] = a;
 }
 
-// ---- packed records ----------------------------------------------------------------------------------------
-// rec[i] = ((low & 0xFFFF) | (high - low) << 16, id) for slots of kSegPacked segments ((0, id) elsewhere)
-__global__ __launch_bounds__(kThreads) void k_pack_records(const uint2 *__restrict__ se,
-                                                           const uint32_t *__restrict__ id,
-                                                           const SegDesc *__restrict__ seg, uint32_t nseg,
-                                                           uint2 *__restrict__ rec, size_t n) {
-  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
-  uint32_t lo = 0, hi = nseg;  // last segment with begin <= i
-  while (hi - lo > 1) {
-    const uint32_t m = (lo + hi) >> 1;
-    if ((size_t)seg[m].begin <= i) lo = m; else hi = m;
-  }
-  const SegDesc d = seg[lo];
-  uint32_t r = 0;
-  if (d.shift & kSegPacked) {
-    const uint2 e = se[i];
-    r = (e.x & 0xFFFFu) | ((e.y - e.x) << 16);
-  }
-  rec[i] = make_uint2(r, id[i]);
-}
-
 inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0) {
   size_t nb = (n + (size_t)per_block - 1) / (size_t)per_block;
   if (nb < 1) nb = 1;
@@ -328,32 +436,15 @@ inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0) {
 int launch_max_cell(const uint32_t *d_table, size_t nentries, uint32_t *d_out, hipStream_t s) {
   BIVX_HIP(hipMemsetAsync(d_out, 0, 4, s));
   if (nentries < 2) return 0;
-  hipLaunchKernelGGL(k_max_cell, dim3(grid_for(nentries, kThreads * 8, 2048)), dim3(kThreads), 0, s, d_table, nentries, d_out);
+  hipLaunchKernelGGL(k_max_cell, dim3(grid_for(nentries, kThreads * 8, 512)), dim3(kThreads), 0, s, d_table, nentries, d_out);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_max_u32(const uint32_t *d_in, size_t n, uint32_t *d_out, hipStream_t s) {
-  BIVX_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t), s));
+int launch_max_chrom_type(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t *d_out2, hipStream_t s) {
+  BIVX_HIP(hipMemsetAsync(d_out2, 0, 2 * sizeof(uint32_t), s));
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_max_u32, dim3(grid_for(n, kThreads * 8, 2048)), dim3(kThreads), 0, s, d_in, n, d_out);
-  BIVX_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_max_u8(const uint8_t *d_in, size_t n, uint32_t *d_out, hipStream_t s) {
-  BIVX_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t), s));
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(k_max_u8, dim3(grid_for(n, kThreads * 16, 2048)), dim3(kThreads), 0, s, d_in, n, d_out);
-  BIVX_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_make_vchrom(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t ntypes, uint32_t *d_vchrom,
-                       hipStream_t s) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(k_make_vchrom, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_chrom, d_type, n, ntypes,
-                     d_vchrom);
+  hipLaunchKernelGGL(k_max_chrom_type, dim3(grid_for(n, kThreads * 16, 512)), dim3(kThreads), 0, s, d_chrom, d_type, n, d_out2);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -366,26 +457,37 @@ int launch_gather_u8(const uint8_t *d_src, const uint32_t *d_ids, size_t n, size
   return 0;
 }
 
-int launch_bin_stats(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n,
-                     uint32_t nchrom, BinStats *d_stats, hipStream_t s) {
-  const uint32_t nent = nchrom * kLenBins;
+int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
+                     const uint32_t *d_high, size_t n, uint32_t nparts, BinStats *d_stats, hipStream_t s) {
+  const uint32_t nent = nparts * kLenBins;
   hipLaunchKernelGGL(k_init_stats, dim3(grid_for(nent, kThreads)), dim3(kThreads), 0, s, d_stats, nent);
   if (n) {
-    const unsigned nb = grid_for(n, kThreads * 16, 2048);
+    const unsigned nb = grid_for(n, kStatsThreads * 8, 1024);
     if (nent <= kStatsLdsEntries)
-      hipLaunchKernelGGL(k_bin_stats<true>, dim3(nb), dim3(kThreads), 0, s, d_chrom, d_low, d_high, n, nchrom, d_stats);
+      hipLaunchKernelGGL(k_bin_stats<true>, dim3(nb), dim3(kStatsThreads), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
+                         nent, d_stats);
     else
-      hipLaunchKernelGGL(k_bin_stats<false>, dim3(nb), dim3(kThreads), 0, s, d_chrom, d_low, d_high, n, nchrom, d_stats);
+      hipLaunchKernelGGL(k_bin_stats<false>, dim3(nb), dim3(kStatsThreads), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
+                         nent, d_stats);
   }
   BIVX_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_make_segkeys(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n,
-                        const uint32_t *d_bin2seg, uint32_t *d_segkey, uint32_t *d_ids, hipStream_t s) {
+int launch_make_keys(int mode, const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
+                     const uint32_t *d_high, size_t n, const uint32_t *d_bin2seg, const uint2 *d_segkey,
+                     const uint32_t *d_ids, uint32_t *d_keys, hipStream_t s) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_make_segkeys, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_chrom, d_low, d_high, n,
-                     d_bin2seg, d_segkey, d_ids);
+  const dim3 grid(grid_for(n, kThreads)), block(kThreads);
+  if (mode == kKeyDense)
+    hipLaunchKernelGGL(k_make_keys<kKeyDense>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
+                       d_segkey, d_ids, d_keys);
+  else if (mode == kKeyLow)
+    hipLaunchKernelGGL(k_make_keys<kKeyLow>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
+                       d_segkey, d_ids, d_keys);
+  else
+    hipLaunchKernelGGL(k_make_keys<kKeySegOfId>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
+                       d_segkey, d_ids, d_keys);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -398,36 +500,44 @@ size_t radix_scratch_bytes(size_t n) {
 }
 
 int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint32_t **vals_alt, size_t n,
-                     int nbits, void *d_scratch, hipStream_t s) {
-  if (n == 0 || nbits <= 0) return 0;
+                     int nbits, void *d_scratch, bool vals_are_iota, hipStream_t s) {
+  if (n == 0) return 0;
   const uint32_t nblocks = (uint32_t)((n + kTile - 1) / kTile);
   const size_t nh = (size_t)nblocks * kRadix;
   uint32_t *hist = static_cast<uint32_t *>(d_scratch);
   uint32_t *offs = hist + nh;
   void *scan_scr = reinterpret_cast<void *>(((uintptr_t)(offs + nh + 1) + 63) & ~(uintptr_t)63);
-  for (int shift = 0; shift < nbits; shift += kRadixBits) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kThreads), 0, s, *keys, n, shift, hist, nblocks);
+  bool iota = vals_are_iota;
+  // (at least one pass, so that the values exist in memory when they were only implied)
+  for (int shift = 0; shift < nbits || iota; shift += kRadixBits) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, n, shift, hist, nblocks);
     BIVX_TRY(exclusive_scan_u32_u32(hist, offs, nh, scan_scr, s));
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(kThreads), 0, s, *keys, *vals, *keys_alt, *vals_alt, n,
-                       shift, offs, nblocks);
+    if (iota)
+      hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, *vals, *keys_alt,
+                         *vals_alt, n, shift, offs, nblocks);
+    else
+      hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, *vals, *keys_alt,
+                         *vals_alt, n, shift, offs, nblocks);
     BIVX_HIP(hipGetLastError());
+    iota = false;
     uint32_t *t = *keys; *keys = *keys_alt; *keys_alt = t;
     t = *vals; *vals = *vals_alt; *vals_alt = t;
   }
   return 0;
 }
 
-int launch_gather_u32(const uint32_t *d_src, const uint32_t *d_idx, uint32_t *d_dst, size_t n, hipStream_t s) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_src, d_idx, d_dst, n);
-  BIVX_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_gather_se(const uint32_t *d_low, const uint32_t *d_high, const uint32_t *d_idx, uint2 *d_se, size_t n,
-                     hipStream_t s) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(k_gather_se, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_low, d_high, d_idx, d_se, n);
+int launch_finalize(const uint32_t *d_keys, const uint32_t *d_ids, const uint32_t *d_low, const uint32_t *d_high,
+                    const SegDesc *d_seg, const uint2 *d_segkey, uint32_t nseg, uint2 *d_se, uint2 *d_rec, size_t n,
+                    hipStream_t s) {
+  if (n == 0 || nseg == 0) return 0;
+  const uint32_t nchunks = grid_for(n, kThreads);
+  const unsigned grid = ((nchunks + 7u) / 8u) * 8u;
+  if (d_keys)
+    hipLaunchKernelGGL(k_finalize<true>, dim3(grid), dim3(kThreads), 0, s, d_keys, d_ids, d_low, d_high, d_seg, d_segkey, nseg,
+                       d_se, d_rec, n, nchunks);
+  else
+    hipLaunchKernelGGL(k_finalize<false>, dim3(grid), dim3(kThreads), 0, s, d_keys, d_ids, d_low, d_high, d_seg, d_segkey,
+                       nseg, d_se, d_rec, n, nchunks);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -437,15 +547,6 @@ int launch_build_table(const uint2 *d_se, const SegDesc *d_seg, uint32_t nseg, u
   if (nentries == 0) return 0;
   hipLaunchKernelGGL(k_build_table, dim3(grid_for(nentries, kThreads)), dim3(kThreads), 0, s, d_se, d_seg, nseg,
                      d_table, nentries);
-  BIVX_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_pack_records(const uint2 *d_se, const uint32_t *d_id, const SegDesc *d_seg, uint32_t nseg, uint2 *d_rec,
-                        size_t n, hipStream_t s) {
-  if (n == 0 || nseg == 0) return 0;
-  hipLaunchKernelGGL(k_pack_records, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_se, d_id, d_seg, nseg, d_rec,
-                     n);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

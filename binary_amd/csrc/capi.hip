@@ -43,7 +43,19 @@ struct bivx_index {
   uint8_t *d_type = nullptr;  // svtype per interval (bivx_append_typed); allocated with the first typed append
   bool typed = false;         // some append carried types
   size_t n = 0, cap = 0;
-  // built index
+  // built index. The arrays live in grow-only device blocks that a rebuild reuses (bivx_clear keeps them too): a build
+  // of 10 M intervals otherwise spends as long in hipMalloc / hipFree — which synchronises the device — as in kernels.
+  struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+  };
+  DevBuf b_se, b_rec, b_table, b_seg, b_rng;  // what the pointers below point into
+  DevBuf b_keys[2], b_ids[2];                 // sort buffers; the ids end up in one of b_ids and stay there (d_id)
+  DevBuf b_misc, b_radix;                     // build temporaries: statistics, key tables, histogram scratch
+  uint32_t *h_scalars = nullptr;              // pinned: the build's few read-backs (max ids, largest cell)
+  // bivx_append_dev copies on the CALLER's stream; the build waits for those copies on its own stream through events
+  // instead of synchronising the device
+  std::vector<hipEvent_t> ev_pending, ev_free;
   bool built = false;
   uint2 *d_se = nullptr;
   uint2 *d_rec = nullptr;
@@ -180,13 +192,8 @@ void drop_block_cache(const bivx_index *idx) {
   idx->cache_bytes = 0;
 }
 
+// the index is no longer searchable; its device blocks stay for the next build
 void free_built(bivx_index *idx) {
-  (void)hipFree(idx->d_se);
-  (void)hipFree(idx->d_rec);
-  (void)hipFree(idx->d_id);
-  (void)hipFree(idx->d_table);
-  (void)hipFree(idx->d_seg);
-  (void)hipFree(idx->d_chrom_rng);
   idx->d_se = nullptr;
   idx->d_rec = nullptr;
   idx->d_id = nullptr;
@@ -198,6 +205,45 @@ void free_built(bivx_index *idx) {
   idx->max_segs.clear();
   idx->nentries = 0;
   idx->built = false;
+}
+
+void release_build_blocks(bivx_index *idx) {
+  for (bivx_index::DevBuf *b : {&idx->b_se, &idx->b_rec, &idx->b_table, &idx->b_seg, &idx->b_rng, &idx->b_keys[0],
+                                &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix}) {
+    (void)hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+  }
+}
+
+// grow-only: a block that is large enough is handed back as it is
+int ensure_block(bivx_index::DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return 0;
+  (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = (bytes + 255) & ~(size_t)255;
+  BIVX_HIP(hipMalloc(&b.p, want ? want : 256));
+  b.cap = want ? want : 256;
+  return 0;
+}
+
+// the copies of a bivx_append*_dev call were just enqueued on `s`: the next build must come after them
+int note_device_append(bivx_index *idx, hipStream_t s) {
+  hipEvent_t ev = nullptr;
+  if (!idx->ev_free.empty()) {
+    ev = idx->ev_free.back();
+    idx->ev_free.pop_back();
+  } else {
+    BIVX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  if (hipEventRecord(ev, s) != hipSuccess) {  // (e.g. a stream that is being captured: fall back to a full wait)
+    idx->ev_free.push_back(ev);
+    BIVX_HIP(hipDeviceSynchronize());
+    return 0;
+  }
+  idx->ev_pending.push_back(ev);
+  return 0;
 }
 
 int ensure_capacity(bivx_index *idx, size_t need) {
@@ -221,6 +267,8 @@ int ensure_capacity(bivx_index *idx, size_t need) {
       // Earlier bivx_append_dev calls copy on the CALLER's streams, which idx->stream is not ordered after: wait
       // for the whole device before the old arrays are read and freed (growth doubles, so this is rare).
       BIVX_HIP(hipDeviceSynchronize());
+      for (hipEvent_t ev : idx->ev_pending) idx->ev_free.push_back(ev);  // (all of them have happened now)
+      idx->ev_pending.clear();
       BIVX_HIP(hipMemcpyAsync(c, idx->d_chrom, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
       BIVX_HIP(hipMemcpyAsync(l, idx->d_low, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
       BIVX_HIP(hipMemcpyAsync(h, idx->d_high, idx->n * 4, hipMemcpyDeviceToDevice, idx->stream));
@@ -270,6 +318,7 @@ int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, con
     BIVX_HIP(hipMemsetAsync(idx->d_type + idx->n, 0, n, s));
   }
   if (kind == hipMemcpyHostToDevice) BIVX_HIP(hipStreamSynchronize(s));  // caller may reuse its buffers
+  else BIVX_TRY(note_device_append(idx, s));
   idx->n += n;
   idx->built = false;
   return 0;
@@ -281,6 +330,10 @@ struct ClassPlan {
   std::vector<uint32_t> chrom_seg;     // nchrom + 1
   uint64_t nentries = 0;
   uint32_t max_low = 0;
+  // sort keys: segment s owns the key range [segkey[s].x, segkey[s].x + (last - base)] (segkey[s].y = base), so that
+  // ONE 32-bit key orders by (segment, low); key_span is the sum of the ranges (> 2^32: no such key exists)
+  std::vector<uint2> segkey;
+  uint64_t key_span = 0;
 };
 
 // Chooses, per chromosome, how to cut the 33 length bins into classes. A class is searched with two
@@ -369,6 +422,12 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &pl
   }
   plan.chrom_seg[nchrom] = (uint32_t)plan.segs.size();
   plan.nentries = table_off;
+  plan.segkey.resize(plan.segs.size());
+  plan.key_span = 0;
+  for (size_t k = 0; k < plan.segs.size(); ++k) {
+    plan.segkey[k] = make_uint2((uint32_t)plan.key_span, plan.segs[k].base);  // (meaningless once the sum passes 2^32)
+    plan.key_span += (uint64_t)plan.segs[k].last - plan.segs[k].base + 1u;
+  }
   return 0;
 }
 
@@ -561,6 +620,10 @@ void bivx_destroy(bivx_index *idx) {
   idx->mailboxes.clear();
   drop_block_cache(idx);
   free_built(idx);
+  release_build_blocks(idx);
+  if (idx->h_scalars) (void)hipHostFree(idx->h_scalars);
+  for (hipEvent_t ev : idx->ev_pending) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : idx->ev_free) (void)hipEventDestroy(ev);
   (void)hipFree(idx->d_chrom);
   (void)hipFree(idx->d_low);
   (void)hipFree(idx->d_high);
@@ -626,8 +689,13 @@ int bivx_build(bivx_index *idx) {
   BIVX_GUARD(idx);
   const auto t0 = std::chrono::steady_clock::now();
   hipStream_t s = idx->stream;
-  // appends made with bivx_append_dev on a caller stream must be complete before we read them
-  BIVX_HIP(hipDeviceSynchronize());
+  // appends made with bivx_append_dev on a caller stream must be complete before they are read: the build stream waits
+  // for their events (the host does not)
+  for (hipEvent_t ev : idx->ev_pending) {
+    BIVX_HIP(hipStreamWaitEvent(s, ev, 0));
+    idx->ev_free.push_back(ev);
+  }
+  idx->ev_pending.clear();
   {
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     // on the build stream, which is synchronised before bivx_build returns (a plain hipMemset runs on the null
@@ -636,53 +704,46 @@ int bivx_build(bivx_index *idx) {
   }
   free_built(idx);
   const size_t n = idx->n;
-  TempPool tmp(idx);
+  if (!idx->h_scalars) BIVX_HIP(hipHostMalloc((void **)&idx->h_scalars, 64, hipHostMallocDefault));
+  volatile uint32_t *hs = idx->h_scalars;
 
-  // 1. number of chromosome ids
-  uint32_t *d_scalar = nullptr;
-  uint32_t max_cell = 0;  // (read back at the end of the build)
-  BIVX_TRY(tmp.alloc(&d_scalar, 1));
-  BIVX_TRY(launch_max_u32(idx->d_chrom, n, d_scalar, s));
-  uint32_t max_chrom = 0;
-  BIVX_HIP(hipMemcpyAsync(&max_chrom, d_scalar, 4, hipMemcpyDeviceToHost, s));
-  BIVX_HIP(hipStreamSynchronize(s));
+  // 1. largest chromosome id and svtype, one pass and one read-back. Interval types (bivx_append_typed): the index is
+  // partitioned by (chromosome, svtype) — the "virtual chromosome" chrom * ntypes + svtype takes the chromosome's place
+  // in everything below, so a query that asks for one type walks only that type's segments and pays nothing per
+  // candidate (the svtype filter of mapper.hpp:153-156, done by the layout instead of by three trees)
+  BIVX_TRY(ensure_block(idx->b_misc, 256));
+  uint32_t *d_scalar = static_cast<uint32_t *>(idx->b_misc.p);  // [0] max chromosome, [1] max svtype, [2] largest cell
+  uint32_t max_chrom = 0, max_type = 0;
+  if (n) {
+    BIVX_TRY(launch_max_chrom_type(idx->d_chrom, idx->typed ? idx->d_type : nullptr, n, d_scalar, s));
+    BIVX_HIP(hipMemcpyAsync(idx->h_scalars, d_scalar, 8, hipMemcpyDeviceToHost, s));
+    BIVX_HIP(hipStreamSynchronize(s));
+    max_chrom = hs[0];
+    max_type = hs[1];
+  }
   if (n && max_chrom >= BIVX_MAX_CHROMS) {
     set_error("chromosome id %u exceeds BIVX_MAX_CHROMS", max_chrom);
     return BIVX_E_RANGE;
   }
   const uint32_t nchrom = n ? max_chrom + 1 : 0;
-  // 1b. interval types (bivx_append_typed): the index is partitioned by (chromosome, svtype) — a "virtual
-  // chromosome" id chrom * ntypes + svtype takes the chromosome's place in everything below, so a query that asks
-  // for one type walks only that type's segments and pays nothing per candidate (the svtype filter of
-  // mapper.hpp:153-156, done by the layout instead of by three trees)
-  uint32_t ntypes = 1;
-  const uint32_t *d_part = idx->d_chrom;  // what partitions the index
-  if (n && idx->typed) {
-    uint32_t max_type = 0;
-    BIVX_TRY(launch_max_u8(idx->d_type, n, d_scalar, s));
-    BIVX_HIP(hipMemcpyAsync(&max_type, d_scalar, 4, hipMemcpyDeviceToHost, s));
-    BIVX_HIP(hipStreamSynchronize(s));
-    ntypes = max_type + 1;
-    if (ntypes > 1) {
-      if ((uint64_t)nchrom * ntypes > BIVX_MAX_CHROMS) {
-        set_error("%u chromosome ids x %u interval types exceed BIVX_MAX_CHROMS", nchrom, ntypes);
-        return BIVX_E_RANGE;
-      }
-      uint32_t *d_v = nullptr;
-      BIVX_TRY(tmp.alloc(&d_v, n));
-      BIVX_TRY(launch_make_vchrom(idx->d_chrom, idx->d_type, n, ntypes, d_v, s));
-      d_part = d_v;
-    }
+  const uint32_t ntypes = max_type + 1;
+  if ((uint64_t)nchrom * ntypes > BIVX_MAX_CHROMS) {
+    set_error("%u chromosome ids x %u interval types exceed BIVX_MAX_CHROMS", nchrom, ntypes);
+    return BIVX_E_RANGE;
   }
+  const uint8_t *d_type = ntypes > 1 ? idx->d_type : nullptr;  // what partitions the index besides the chromosome
   const uint32_t nvchrom = nchrom * ntypes;
 
-  // 2. per (chromosome, length bin) statistics -> host
+  // 2. per (partition, length bin) statistics -> host
   std::vector<BinStats> st((size_t)nvchrom * kLenBins);
   ClassPlan plan;
+  const size_t stats_bytes = (st.size() * sizeof(BinStats) + 255) & ~(size_t)255;
+  const size_t b2s_bytes = (st.size() * 4 + 255) & ~(size_t)255;
   if (n) {
-    BinStats *d_stats = nullptr;
-    BIVX_TRY(tmp.alloc(&d_stats, st.size()));
-    BIVX_TRY(launch_bin_stats(d_part, idx->d_low, idx->d_high, n, nvchrom, d_stats, s));
+    BIVX_TRY(ensure_block(idx->b_misc, 256 + stats_bytes + b2s_bytes));
+    d_scalar = static_cast<uint32_t *>(idx->b_misc.p);
+    BinStats *d_stats = reinterpret_cast<BinStats *>(static_cast<char *>(idx->b_misc.p) + 256);
+    BIVX_TRY(launch_bin_stats(idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, nvchrom, d_stats, s));
     BIVX_HIP(hipMemcpyAsync(st.data(), d_stats, st.size() * sizeof(BinStats), hipMemcpyDeviceToHost, s));
     BIVX_HIP(hipStreamSynchronize(s));
   }
@@ -703,57 +764,70 @@ int bivx_build(bivx_index *idx) {
       max_segs[t] = std::max(max_segs[t], cs[t + 1] - cs[t]);
     }
   }
-  BIVX_HIP(hipMalloc((void **)&idx->d_chrom_rng, rng.size() * sizeof(uint2)));
+  // (descriptors and their sort keys in one block: [SegDesc x nseg | (keybase, base) x nseg])
+  const size_t seg_bytes = ((size_t)(nseg ? nseg : 1) * sizeof(SegDesc) + 255) & ~(size_t)255;
+  BIVX_TRY(ensure_block(idx->b_rng, rng.size() * sizeof(uint2)));
+  BIVX_TRY(ensure_block(idx->b_seg, seg_bytes + (size_t)(nseg ? nseg : 1) * sizeof(uint2)));
+  idx->d_chrom_rng = static_cast<uint2 *>(idx->b_rng.p);
+  idx->d_seg = static_cast<SegDesc *>(idx->b_seg.p);
+  uint2 *d_segkey = reinterpret_cast<uint2 *>(static_cast<char *>(idx->b_seg.p) + seg_bytes);
   BIVX_HIP(hipMemcpyAsync(idx->d_chrom_rng, rng.data(), rng.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
-  BIVX_HIP(hipMalloc((void **)&idx->d_seg, (size_t)(nseg ? nseg : 1) * sizeof(SegDesc)));
-  if (nseg)
+  if (nseg) {
     BIVX_HIP(hipMemcpyAsync(idx->d_seg, plan.segs.data(), (size_t)nseg * sizeof(SegDesc), hipMemcpyHostToDevice, s));
+    BIVX_HIP(hipMemcpyAsync(d_segkey, plan.segkey.data(), (size_t)nseg * sizeof(uint2), hipMemcpyHostToDevice, s));
+  }
 
+  uint32_t max_cell = 0;
   if (n) {
-    // 4. sort keys
-    uint32_t *d_bin2seg = nullptr, *d_segkey = nullptr, *kA = nullptr, *kB = nullptr, *vA = nullptr, *vB = nullptr;
-    void *d_rscr = nullptr;
-    BIVX_TRY(tmp.alloc(&d_bin2seg, plan.bin2seg.size()));
-    BIVX_TRY(tmp.alloc(&d_segkey, n));
-    BIVX_TRY(tmp.alloc(&kA, n));
-    BIVX_TRY(tmp.alloc(&kB, n));
-    BIVX_TRY(tmp.alloc(&vA, n));
-    BIVX_TRY(tmp.alloc(&vB, n));
-    {
-      uint8_t *p = nullptr;
-      BIVX_TRY(tmp.alloc(&p, radix_scratch_bytes(n)));
-      d_rscr = p;
+    // 4. stable sort to (segment, low, id). One 32-bit key holds (segment, low) while the segments' coordinate spans add
+    // up to less than 2^32 (see ClassPlan::segkey): then ONE sort does it and `low` comes back out of the sorted key.
+    // Otherwise two: by low, then by the segment of the ids as the first sort left them.
+    for (int k = 0; k < 2; ++k) {
+      BIVX_TRY(ensure_block(idx->b_keys[k], n * 4));
+      BIVX_TRY(ensure_block(idx->b_ids[k], n * 4));
     }
+    BIVX_TRY(ensure_block(idx->b_radix, radix_scratch_bytes(n)));
+    uint32_t *kA = static_cast<uint32_t *>(idx->b_keys[0].p), *kB = static_cast<uint32_t *>(idx->b_keys[1].p);
+    uint32_t *vA = static_cast<uint32_t *>(idx->b_ids[0].p), *vB = static_cast<uint32_t *>(idx->b_ids[1].p);
+    uint32_t *d_bin2seg = reinterpret_cast<uint32_t *>(static_cast<char *>(idx->b_misc.p) + 256 + stats_bytes);
     BIVX_HIP(hipMemcpyAsync(d_bin2seg, plan.bin2seg.data(), plan.bin2seg.size() * 4, hipMemcpyHostToDevice, s));
-    BIVX_TRY(launch_make_segkeys(d_part, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey, vA, s));
-    BIVX_HIP(hipMemcpyAsync(kA, idx->d_low, n * 4, hipMemcpyDeviceToDevice, s));
-    // 5. stable sort by low, then by segment (LSD): final order (segment, low, id)
-    BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), d_rscr, s));
-    if (nseg > 1) {
-      BIVX_TRY(launch_gather_u32(d_segkey, vA, kA, n, s));
-      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), d_rscr, s));
+    const bool dense = plan.key_span <= 0xFFFFFFFFull && !std::getenv("BIVX_BUILD_TWO_STAGE");  // (env: test knob)
+    if (dense) {
+      BIVX_TRY(launch_make_keys(kBuildKeyDense, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
+                                nullptr, kA, s));
+      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for((uint32_t)(plan.key_span - 1)), idx->b_radix.p, true, s));
+    } else {
+      BIVX_TRY(launch_make_keys(kBuildKeyLow, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
+                                nullptr, kA, s));
+      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), idx->b_radix.p, true, s));
+      if (nseg > 1) {
+        BIVX_TRY(launch_make_keys(kBuildKeySegOfId, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg,
+                                  d_segkey, vA, kA, s));
+        BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), idx->b_radix.p, false, s));
+      }
     }
-    // 6. sorted (low, high) pairs; ids
-    // two spare slots: query lanes read (low, high) pairs two at a time (16 B), so the pair holding the last
-    // slot may reach one slot past the end
-    BIVX_HIP(hipMalloc((void **)&idx->d_se, (n + 2) * sizeof(uint2)));
+    idx->d_id = vA;  // (one of the two id blocks; it stays the index's until the next build)
+    // 5. sorted (low, high) pairs and packed (record, id) pairs
+    // two spare slots each: query lanes read pairs two at a time (16 B), so the pair holding the last slot may reach
+    // one slot past the end
+    BIVX_TRY(ensure_block(idx->b_se, (n + 2) * sizeof(uint2)));
+    BIVX_TRY(ensure_block(idx->b_rec, (n + 2) * sizeof(uint2)));
+    idx->d_se = static_cast<uint2 *>(idx->b_se.p);
+    idx->d_rec = static_cast<uint2 *>(idx->b_rec.p);
     BIVX_HIP(hipMemsetAsync(idx->d_se + n, 0xFF, 2 * sizeof(uint2), s));
-    BIVX_TRY(launch_gather_se(idx->d_low, idx->d_high, vA, idx->d_se, n, s));
-    idx->d_id = vA;
-    tmp.release(vA);
-    // 7. bucket directory
-    // (+3 spare entries: query lanes read directory entries four at a time)
-    BIVX_HIP(hipMalloc((void **)&idx->d_table, ((size_t)plan.nentries + 3) * 4));
+    BIVX_HIP(hipMemsetAsync(idx->d_rec + n, 0, 2 * sizeof(uint2), s));
+    BIVX_TRY(launch_finalize(dense ? kA : nullptr, idx->d_id, idx->d_low, idx->d_high, idx->d_seg, d_segkey, nseg, idx->d_se,
+                             idx->d_rec, n, s));
+    // 6. bucket directory (+3 spare entries: query lanes read directory entries four at a time)
+    BIVX_TRY(ensure_block(idx->b_table, ((size_t)plan.nentries + 3) * 4));
+    idx->d_table = static_cast<uint32_t *>(idx->b_table.p);
     BIVX_HIP(hipMemsetAsync(idx->d_table + plan.nentries, 0xFF, 3 * 4, s));
     BIVX_TRY(launch_build_table(idx->d_se, idx->d_seg, nseg, idx->d_table, plan.nentries, s));
-    BIVX_TRY(launch_max_cell(idx->d_table, plan.nentries, d_scalar, s));
-    BIVX_HIP(hipMemcpyAsync(&max_cell, d_scalar, 4, hipMemcpyDeviceToHost, s));
-    // 8. packed (record, id) pairs for the segments that allow them (+2 spare: read two at a time)
-    BIVX_HIP(hipMalloc((void **)&idx->d_rec, (n + 2) * sizeof(uint2)));
-    BIVX_HIP(hipMemsetAsync(idx->d_rec + n, 0, 2 * sizeof(uint2), s));
-    BIVX_TRY(launch_pack_records(idx->d_se, idx->d_id, idx->d_seg, nseg, idx->d_rec, n, s));
+    BIVX_TRY(launch_max_cell(idx->d_table, plan.nentries, d_scalar + 2, s));
+    BIVX_HIP(hipMemcpyAsync(idx->h_scalars + 2, d_scalar + 2, 4, hipMemcpyDeviceToHost, s));
   }
   BIVX_HIP(hipStreamSynchronize(s));
+  if (n) max_cell = hs[2];
   idx->nchrom = nchrom;
   idx->nseg = nseg;
   idx->ntypes = ntypes;

@@ -5,7 +5,7 @@ interval_tree.hpp:230-260) on a BASELINE config's interval set: device-resident 
     python3 tools/build_bench.py [--config 3] [--reps 20] [--typed]
 
 Prints one JSON line: wall time of bivx_build as the library reports it (host clock around the whole call, syncs
-included), GPU time between HIP events around the call, and the build roofline: algorithmic bytes 34 N
+included) and the build roofline: algorithmic bytes 34 N
 (12 N in: chrom, low, high; out: se 8 N + id 4 N + rec 8 N + directory ~2 N) over the HBM peak.
 Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split (tools/kstats.py prints it)."""
 import argparse
@@ -39,26 +39,20 @@ d_lo, d_hi = to(low), to(high)
 d_c = None if chrom is None else to(chrom)
 d_t = torch.from_numpy((np.arange(N) % 3 + 1).astype(np.uint8)).to(dev) if a.typed else None
 
-wall, gpu = [], []
+wall = []
 with IntervalIndex(0) as idx:
     for r in range(a.reps + 2):
         idx.clear()
         idx.insert_node(d_lo, d_hi, d_c, svtype=d_t)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
         idx.build()
-        e1.record()
-        torch.cuda.synchronize()
         if r >= 2:  # the first builds allocate the index's pooled blocks
             wall.append(idx.stats()["build_ms"])
-            gpu.append(e0.elapsed_time(e1))
     st = idx.stats()
 b_alg = 34 * N
 ms = float(np.median(wall))
 print(json.dumps({"config": a.config, "intervals": N, "typed": bool(a.typed), "reps": a.reps,
                   "build_ms_median": ms, "build_ms_min": float(np.min(wall)), "build_ms_max": float(np.max(wall)),
-                  "event_ms_median": float(np.median(gpu)),
                   "intervals_per_s": N / ms * 1e3, "algorithmic_bytes": b_alg,
                   "roofline": {"bound": "hbm", "achieved_GBs": b_alg / ms / 1e6, "peak_GBs": 8000.0,
                                "frac": b_alg / ms / 1e6 / 8000.0},
