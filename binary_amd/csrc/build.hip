@@ -19,20 +19,26 @@ __device__ __forceinline__ uint32_t len_bin(uint32_t low, uint32_t high, uint32_
 }
 
 // ---- per (chromosome, length bin) statistics ---------------------------------------------------------
-// One pass over the appended columns. A wavefront takes 64 intervals at a time and aggregates them by (partition,
-// length bin) BEFORE anything touches a shared table: for every distinct key among its 64 lanes (a scalar loop over
-// ballots) the count is a popcount and min / max are DPP reductions, and one lane adds the result to the table. The
-// first form did five LDS atomics per interval, all of a workgroup's lanes on the ~10 words of one chromosome's common
-// length bins: the LDS serialises same-address atomics, so 10 M intervals took 169 us — 0.7 TB/s for a 120 MB read.
+// One pass over the appended columns. Per interval ONE LDS atomic (its key's count). The three extrema hardly ever
+// change once a table entry has seen a few hundred intervals: every lane READS its entry (same-address LDS reads
+// broadcast, they do not serialise) and only a wavefront in which some lane would improve an entry reduces those lanes'
+// values (DPP) and lets one lane issue the atomics. Steps measured at 10 M intervals (a 120 MB read): five LDS atomics
+// per interval, one chunk of 64 per wavefront and trip: 169 us; everything reduced per distinct key in every wavefront:
+// 149; counts by a scalar loop over the wavefront's keys + the conditional extrema: 152, with four chunks in flight 103.
 
 constexpr uint32_t kStatsLdsEntries = 3300;  // (partition, bin) pairs privatised in LDS (100 partitions: 66 KB)
 constexpr int kStatsThreads = 512;
+constexpr int kStatsUnroll = 4;            // chunks of 64 intervals a wavefront has in flight
 
 // the partition ("virtual chromosome") of interval i: chrom * ntypes + svtype (include/bivx.h, bivx_append_typed)
 __device__ __forceinline__ uint32_t part_of(const uint32_t *__restrict__ chrom, const uint8_t *__restrict__ type,
                                             uint32_t ntypes, size_t i) {
   const uint32_t c = chrom ? chrom[i] : 0u;
   return type ? c * ntypes + type[i] : c;
+}
+
+__device__ __forceinline__ uint32_t peek(const uint32_t *p) {  // (a plain read the compiler may not keep in a register)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <bool USE_LDS>
@@ -48,33 +54,54 @@ __global__ __launch_bounds__(kStatsThreads) void k_bin_stats(const uint32_t *__r
   }
   BinStats *tab = USE_LDS ? lds : stats;
   const uint32_t lane = threadIdx.x & (kWave - 1);
-  // (wavefront-uniform trip count: the reductions below need all 64 lanes)
-  for (size_t i0 = ((size_t)blockIdx.x * kStatsThreads + (threadIdx.x & ~(uint32_t)(kWave - 1))); i0 < n;
-       i0 += (size_t)gridDim.x * kStatsThreads) {
-    const size_t i = i0 + lane;
-    const bool valid = i < n;
-    uint32_t lo = 0, hi = 0, key = 0xFFFFFFFFu, len = 0;
-    if (valid) {
-      lo = low[i];
-      hi = high[i];
-      key = part_of(chrom, type, ntypes, i) * kLenBins + len_bin(lo, hi, len);
-    }
-    uint64_t todo = __ballot(valid);
-    while (todo) {
-      const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)todo) - 1);
-      const bool in = key == k;
-      const uint64_t m = __ballot(in);
-      const uint32_t mn = wave_min(in ? lo : 0xFFFFFFFFu), mx = wave_max(in ? lo : 0u), ml = wave_max(in ? len : 0u);
-      const uint32_t ninv = (uint32_t)__popcll(__ballot(in && lo > hi));
-      if (lane == 0) {
-        BinStats *e = tab + k;
-        atomicAdd(&e->count, (uint32_t)__popcll(m));
-        atomicMin(&e->min_low, mn);
-        atomicMax(&e->max_low, mx);
-        atomicMax(&e->max_len, ml);
-        if (ninv) atomicAdd(&e->n_inverted, ninv);
+  // A wavefront takes kStatsUnroll x 64 consecutive intervals per trip and has all their loads in flight before it looks
+  // at the first (with one chunk per trip the kernel waited for memory: 4 wavefronts per SIMD x 768 bytes each).
+  // (wavefront-uniform trip count: the ballots and reductions below need all 64 lanes)
+  const size_t stride = (size_t)gridDim.x * kStatsThreads * kStatsUnroll;
+  for (size_t i0 = ((size_t)blockIdx.x * kStatsThreads + (threadIdx.x & ~(uint32_t)(kWave - 1))) * kStatsUnroll; i0 < n;
+       i0 += stride) {
+    uint32_t lo_[kStatsUnroll], hi_[kStatsUnroll], part_[kStatsUnroll];
+#pragma unroll
+    for (int u = 0; u < kStatsUnroll; ++u) {
+      const size_t i = i0 + (size_t)u * kWave + lane;
+      lo_[u] = hi_[u] = part_[u] = 0;
+      if (i < n) {
+        lo_[u] = low[i];
+        hi_[u] = high[i];
+        part_[u] = part_of(chrom, type, ntypes, i);
       }
-      todo &= ~m;
+    }
+#pragma unroll
+    for (int u = 0; u < kStatsUnroll; ++u) {
+      const size_t i = i0 + (size_t)u * kWave + lane;
+      const bool valid = i < n;
+      const uint32_t lo = lo_[u], hi = hi_[u];
+      uint32_t key = 0xFFFFFFFFu, len = 0;
+      if (valid) key = part_[u] * kLenBins + len_bin(lo, hi, len);
+      // counts: one LDS atomic per interval (lanes of one key serialise on its word, ~30 cycles for the commonest
+      // length bin — a scalar loop over the wavefront's distinct keys cost more instructions than that)
+      if (valid) {
+        atomicAdd(&tab[key].count, 1u);
+        if (lo > hi) atomicAdd(&tab[key].n_inverted, 1u);
+      }
+      // extrema: only lanes that would improve their entry take part
+      bool better = false;
+      if (valid) {
+        const BinStats *e = tab + key;
+        better = lo < peek(&e->min_low) || lo > peek(&e->max_low) || len > peek(&e->max_len);
+      }
+      uint64_t todo = __ballot(better);
+      while (todo) {
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)todo) - 1);
+        const bool in = better && key == k;
+        const uint32_t mn = wave_min(in ? lo : 0xFFFFFFFFu), mx = wave_max(in ? lo : 0u), ml = wave_max(in ? len : 0u);
+        if (lane == 0) {
+          atomicMin(&tab[k].min_low, mn);
+          atomicMax(&tab[k].max_low, mx);
+          atomicMax(&tab[k].max_len, ml);
+        }
+        todo &= ~__ballot(in);
+      }
     }
   }
   if (USE_LDS) {
@@ -141,18 +168,6 @@ __global__ __launch_bounds__(kThreads) void k_max_chrom_type(const uint32_t *__r
   block_max_to(mt, out + 1);
 }
 
-// largest number of slots any directory cell holds: max over e of table[e + 1] - table[e] (a segment's entries end with
-// its last slot + 1, which is where the next segment's begin: the difference across a boundary is 0)
-__global__ __launch_bounds__(kThreads) void k_max_cell(const uint32_t *__restrict__ table, size_t nentries,
-                                                       uint32_t *__restrict__ out) {
-  uint32_t m = 0;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i + 1 < nentries; i += (size_t)gridDim.x * kThreads) {
-    const uint32_t a = table[i], b = table[i + 1];
-    m = max(m, b > a ? b - a : 0u);
-  }
-  block_max_to(m, out);
-}
-
 __global__ __launch_bounds__(kThreads) void k_gather_u8(const uint8_t *__restrict__ src,
                                                         const uint32_t *__restrict__ ids, size_t n, size_t n_src,
                                                         uint8_t *__restrict__ out) {
@@ -168,6 +183,8 @@ __global__ __launch_bounds__(kThreads) void k_gather_u8(const uint8_t *__restric
 // segment of the ids as they lie after the first.
 enum : int { kKeyDense = 0, kKeyLow = 1, kKeySegOfId = 2 };
 
+// kKeyLow also leaves every interval's segment in seg_of[] (append order), so that the second stage — kKeySegOfId:
+// keys[i] = seg_of[ids[i]] — is one gather of one word (recomputing the segment from the gathered columns was four).
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_make_keys(const uint32_t *__restrict__ chrom,
                                                         const uint8_t *__restrict__ type, uint32_t ntypes,
@@ -176,20 +193,21 @@ __global__ __launch_bounds__(kThreads) void k_make_keys(const uint32_t *__restri
                                                         const uint32_t *__restrict__ bin2seg,
                                                         const uint2 *__restrict__ segkey,  // (keybase, base) per segment
                                                         const uint32_t *__restrict__ ids,   // kKeySegOfId: sorted ids
+                                                        uint32_t *__restrict__ seg_of,      // kKeyLow: out; kKeySegOfId: in
                                                         uint32_t *__restrict__ keys) {
   const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
-  if (MODE == kKeyLow) {
-    keys[i] = low[i];
+  if (MODE == kKeySegOfId) {
+    keys[i] = seg_of[ids[i]];
     return;
   }
-  const size_t j = MODE == kKeySegOfId ? ids[i] : i;
   uint32_t len;
-  const uint32_t lo = low[j];
-  const uint32_t b = len_bin(lo, high[j], len);
-  const uint32_t seg = bin2seg[(size_t)part_of(chrom, type, ntypes, j) * kLenBins + b];
-  if (MODE == kKeySegOfId) {
-    keys[i] = seg;
+  const uint32_t lo = low[i];
+  const uint32_t b = len_bin(lo, high[i], len);
+  const uint32_t seg = bin2seg[(size_t)part_of(chrom, type, ntypes, i) * kLenBins + b];
+  if (MODE == kKeyLow) {
+    keys[i] = lo;
+    seg_of[i] = seg;
   } else {
     const uint2 k = segkey[seg];
     keys[i] = k.x + (lo - k.y);
@@ -248,13 +266,53 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
   }
 }
 
+// offs[d][b] = number of keys with digit d in the tiles before b (one workgroup per digit walks its row of the
+// histogram); totals[d] = the digit's keys in all tiles. The scatter kernel adds the digits before d itself, so one
+// pass is three launches — histogram, rows, scatter — where a device-wide scan of the whole table took three by itself.
+__global__ __launch_bounds__(kThreads) void k_radix_rows(const uint32_t *__restrict__ hist, uint32_t *__restrict__ offs,
+                                                         uint32_t *__restrict__ totals, uint32_t nblocks) {
+  __shared__ uint32_t s_w[kThreads / kWave];
+  const uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
+  uint32_t *out = offs + (size_t)blockIdx.x * nblocks;
+  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (uint32_t c = 0; c < nblocks; c += kThreads * 4) {
+    const uint32_t i = c + threadIdx.x * 4;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = i + k < nblocks ? row[i + k] : 0u;
+      sum += v[k];
+    }
+    const uint32_t incl = wave_scan_incl(sum);
+    if (lane == kWave - 1) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t run = carry + incl - sum, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kThreads / kWave; ++w) {
+      const uint32_t t = s_w[w];
+      if (w < wave) run += t;
+      all += t;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < nblocks) out[i + k] = run;
+      run += v[k];
+    }
+    carry += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 // IOTA: the values are the keys' own indices (first pass of a sort whose values are the ids 0 .. n-1): nothing is read.
 template <bool IOTA>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ keys_in,
                                                                 const uint32_t *__restrict__ vals_in,
                                                                 uint32_t *__restrict__ keys_out,
                                                                 uint32_t *__restrict__ vals_out, size_t n, int shift,
-                                                                const uint32_t *__restrict__ offs, uint32_t nblocks) {
+                                                                const uint32_t *__restrict__ offs,
+                                                                const uint32_t *__restrict__ totals, uint32_t nblocks) {
   __shared__ uint32_t s_key[kTile];
   __shared__ uint32_t s_val[kTile];
   __shared__ uint32_t wcnt[kSortWaves][kRadix];  // per-wave digit counts, then the waves' first positions per digit
@@ -304,15 +362,22 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
       total += c;
     }
   }
-  const uint32_t incl = wave_scan_incl(total);
-  if (lane == kWave - 1) s_wsum[wave] = incl;
-  __syncthreads();
+  // exclusive scan over the 256 values that threads 0 .. 255 hold (the others pass 0)
+  auto excl_scan = [&](uint32_t v) {
+    const uint32_t incl = wave_scan_incl(v);
+    if (lane == kWave - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t ex = incl - v;
+    for (int w = 0; w < wave; ++w) ex += s_wsum[w];
+    __syncthreads();
+    return ex;
+  };
+  const uint32_t excl = excl_scan(total);                                         // the digit's first position in the tile
+  const uint32_t dbase = excl_scan(threadIdx.x < kRadix ? totals[threadIdx.x] : 0u);  // ... and in the whole output
   if (threadIdx.x < kRadix) {
-    uint32_t excl = incl - total;
-    for (int w = 0; w < wave; ++w) excl += s_wsum[w];
 #pragma unroll
     for (int w = 0; w < kSortWaves; ++w) wcnt[w][threadIdx.x] += excl;
-    s_goff[threadIdx.x] = offs[(size_t)threadIdx.x * nblocks + blockIdx.x] - excl;
+    s_goff[threadIdx.x] = dbase + offs[(size_t)threadIdx.x * nblocks + blockIdx.x] - excl;
   }
   __syncthreads();
 #pragma unroll
@@ -354,13 +419,28 @@ __global__ __launch_bounds__(kThreads) void k_gather_intervals(const uint32_t *_
   if (oh) oh[i] = ok ? high[j] : 0u;
 }
 
-// ---- the sorted arrays -------------------------------------------------------------------------------------
+// ---- the sorted arrays and the bucket directory ----------------------------------------------------------
 // se[i] = (low, high) of sorted slot i, rec[i] = its packed record beside its id (kSegPacked segments; (0, id) elsewhere),
 // from the sorted keys and ids in one pass. DENSE: low comes back out of the key (keybase / base of the slot's segment);
 // `high` is the one gather — by id, i.e. in append order, and ids of neighbouring slots are scattered over their
 // chromosome's part of the column. The launch is XCD-aware for it: workgroup b works on chunk (b % 8) * nchunks / 8 + b / 8,
 // so each of the eight L2s (workgroups are dealt round-robin over the XCDs) walks ONE contiguous eighth of the slots and
 // with it one chromosome's 3 MB of `high` at a time, instead of all eight walking all of it.
+//
+// The same pass writes the bucket directory: table[d.table_off + c] = first slot of the segment whose low >= d.base +
+// (c << d.shift), for c in [0, ncell]; entry ncell is the segment's end. Slot i, in cell c_i, is that first slot for every
+// cell after its predecessor's up to its own: the entries (c_{i-1}, c_i] receive i (from entry 0 on if i opens its
+// segment), and the segment's last slot also gives the entries behind its cell the segment's end. Mostly none, one or
+// two entries per slot; a longer stretch of empty cells (a centromere) is written by the slot's whole wavefront, and
+// one of more than kCoopMax entries goes on a short list that k_fill_gaps, launched behind this kernel, works off with
+// the whole grid. (A search per entry — the first form — is a chain of ~20 dependent probes: 66 us for 3 M entries.)
+constexpr uint32_t kInlineFill = 4;         // entries a slot writes by itself
+constexpr uint32_t kCoopMax = 1u << 14;     // entries a wavefront writes for one of its slots
+
+struct Gap {
+  uint32_t first, count, value, pad;
+};
+
 template <bool DENSE>
 __global__ __launch_bounds__(kThreads) void k_finalize(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ ids,
@@ -368,60 +448,111 @@ __global__ __launch_bounds__(kThreads) void k_finalize(const uint32_t *__restric
                                                        const uint32_t *__restrict__ high,
                                                        const SegDesc *__restrict__ seg,
                                                        const uint2 *__restrict__ segkey, uint32_t nseg,
-                                                       uint2 *__restrict__ se, uint2 *__restrict__ rec, size_t n,
+                                                       uint2 *__restrict__ se, uint2 *__restrict__ rec,
+                                                       uint32_t *__restrict__ table, Gap *__restrict__ gaps,
+                                                       uint32_t *__restrict__ ngaps, uint32_t gap_cap, size_t n,
                                                        uint32_t nchunks) {
   const uint32_t per = (nchunks + 7u) / 8u;
   const uint32_t chunk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-  if ((blockIdx.x >> 3) >= per || chunk >= nchunks) return;
+  if ((blockIdx.x >> 3) >= per || chunk >= nchunks) return;  // (workgroup-uniform)
   const size_t i = (size_t)chunk * kThreads + threadIdx.x;
-  if (i >= n) return;
-  uint32_t lo = 0, hi = nseg;  // last segment with begin <= i
-  while (hi - lo > 1) {
-    const uint32_t m = (lo + hi) >> 1;
-    if ((size_t)seg[m].begin <= i) lo = m; else hi = m;
+  if (chunk == 0 && threadIdx.x < 2) {  // the two spare slots behind the arrays (query lanes read pairs of slots)
+    se[n + threadIdx.x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    rec[n + threadIdx.x] = make_uint2(0u, 0u);
   }
-  const uint32_t shift = seg[lo].shift;
-  const uint32_t id = ids[i];
-  uint32_t l;
-  if (DENSE) {
-    const uint2 k = segkey[lo];
-    l = k.y + (keys[i] - k.x);
-  } else {
-    l = low[id];
+  const bool valid = i < n;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  // what this slot writes into the directory: entries [e0, e0 + cnt) = i, and behind a segment's last slot [t0, t0 + tcnt) = end
+  uint32_t e0 = 0, cnt = 0, t0 = 0, tcnt = 0, tval = 0;
+  if (valid) {
+    uint32_t lo = 0, hi = nseg;  // last segment with begin <= i
+    while (hi - lo > 1) {
+      const uint32_t m = (lo + hi) >> 1;
+      if ((size_t)seg[m].begin <= i) lo = m; else hi = m;
+    }
+    const SegDesc d = seg[lo];
+    // (the streams are touched once: non-temporal, so that they leave the L2 to the gathered column)
+    const uint32_t id = __builtin_nontemporal_load(ids + i);
+    uint2 k = make_uint2(0u, 0u);
+    uint32_t l;
+    if (DENSE) {
+      k = segkey[lo];
+      l = k.y + (__builtin_nontemporal_load(keys + i) - k.x);
+    } else {
+      l = low[id];
+    }
+    const uint32_t h = high[id];
+    unsigned long long *se64 = reinterpret_cast<unsigned long long *>(se), *rec64 = reinterpret_cast<unsigned long long *>(rec);
+    const uint32_t r = (d.shift & kSegPacked) ? ((l & 0xFFFFu) | ((h - l) << 16)) : 0u;
+    __builtin_nontemporal_store((unsigned long long)l | (unsigned long long)h << 32, se64 + i);
+    __builtin_nontemporal_store((unsigned long long)r | (unsigned long long)id << 32, rec64 + i);
+    // directory
+    const uint32_t sh = d.shift & 31u;
+    const uint32_t c = (l - d.base) >> sh;
+    uint32_t first = 0;
+    if (i > d.begin) {
+      const uint32_t lp = DENSE ? k.y + (keys[i - 1] - k.x) : low[ids[i - 1]];
+      first = ((lp - d.base) >> sh) + 1u;
+    }
+    e0 = d.table_off + first;
+    cnt = c + 1u - first;  // (0 when the slot shares its predecessor's cell)
+    if (i + 1 == d.end) {
+      t0 = d.table_off + c + 1u;
+      tcnt = d.ncell - c;
+      tval = d.end;
+    }
   }
-  const uint32_t h = high[id];
-  se[i] = make_uint2(l, h);
-  rec[i] = make_uint2((shift & kSegPacked) ? ((l & 0xFFFFu) | ((h - l) << 16)) : 0u, id);
+  const uint32_t val = (uint32_t)i;
+  if (cnt <= kInlineFill)
+    for (uint32_t c = 0; c < cnt; ++c) table[e0 + c] = val;
+  if (tcnt <= kInlineFill)
+    for (uint32_t c = 0; c < tcnt; ++c) table[t0 + c] = tval;
+  // longer stretches: the wavefront writes them, lane by lane (every lane of the wavefront is here)
+  auto cooperative = [&](bool pending, uint32_t b0, uint32_t bc, uint32_t bv) {
+    uint64_t pm = __ballot(pending);
+    while (pm) {
+      const int src = __ffsll((long long)pm) - 1;
+      pm &= pm - 1;
+      const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, src);
+      const uint32_t gc = (uint32_t)__builtin_amdgcn_readlane((int)bc, src);
+      const uint32_t gv = (uint32_t)__builtin_amdgcn_readlane((int)bv, src);
+      if (gc > kCoopMax) {
+        if (lane == 0) {
+          const uint32_t g = atomicAdd(ngaps, 1u);
+          if (g < gap_cap) gaps[g] = Gap{g0, gc, gv, 0u};  // (the capacity covers every stretch there can be)
+        }
+      } else {
+        for (uint32_t c = lane; c < gc; c += kWave) table[g0 + c] = gv;
+      }
+    }
+  };
+  cooperative(cnt > kInlineFill, e0, cnt, val);
+  cooperative(tcnt > kInlineFill, t0, tcnt, tval);
 }
 
-// ---- bucket directory --------------------------------------------------------------------------------------
-// table[d.table_off + c] = first slot in segment whose low >= d.base + (c << d.shift), for c in [0, ncell];
-// entry ncell is the segment end. One thread per directory entry, a binary search each.
+// the listed stretches of directory entries, by the whole grid
+__global__ __launch_bounds__(kThreads) void k_fill_gaps(const Gap *__restrict__ gaps, const uint32_t *__restrict__ ngaps,
+                                                        uint32_t gap_cap, uint32_t *__restrict__ table) {
+  const uint32_t ng = min(*ngaps, gap_cap);
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x, nt = gridDim.x * kThreads;
+  for (uint32_t g = 0; g < ng; ++g) {
+    const Gap gp = gaps[g];
+    for (uint32_t c = t; c < gp.count; c += nt) table[gp.first + c] = gp.value;
+  }
+}
 
-__global__ __launch_bounds__(kThreads) void k_build_table(const uint2 *__restrict__ se,
-                                                          const SegDesc *__restrict__ seg, uint32_t nseg,
-                                                          uint32_t *__restrict__ table, uint64_t nentries) {
-  const uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (e >= nentries) return;
-  // segment owning entry e: last s with table_off <= e (entries of segment s: table_off .. table_off+ncell)
-  uint32_t lo = 0, hi = nseg;
-  while (hi - lo > 1) {
-    const uint32_t m = (lo + hi) >> 1;
-    if ((uint64_t)seg[m].table_off <= e) lo = m; else hi = m;
+// largest number of slots any directory cell holds: max over e of table[e + 1] - table[e] (a segment's entries end with
+// its last slot + 1, which is where the next segment's begin: the difference across a boundary is 0). Also writes the
+// directory's three spare entries (query lanes read entries four at a time).
+__global__ __launch_bounds__(kThreads) void k_max_cell(uint32_t *__restrict__ table, size_t nentries,
+                                                       uint32_t *__restrict__ out) {
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i + 1 < nentries; i += (size_t)gridDim.x * kThreads) {
+    const uint32_t a = table[i], b = table[i + 1];
+    m = max(m, b > a ? b - a : 0u);
   }
-  const SegDesc d = seg[lo];
-  const uint32_t c = (uint32_t)(e - d.table_off);
-  uint32_t a = d.begin, b = d.end;
-  if (c < d.ncell) {
-    const uint32_t x = d.base + (c << (d.shift & 31u));
-    while (a < b) {
-      const uint32_t m = (a + b) >> 1;
-      if (se[m].x < x) a = m + 1; else b = m;
-    }
-  } else {
-    a = d.end;
-  }
-  table[e] = a;
+  if (blockIdx.x == 0 && threadIdx.x < 3) table[nentries + threadIdx.x] = 0xFFFFFFFFu;
+  block_max_to(m, out);
 }
 
 inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0) {
@@ -433,17 +564,8 @@ inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0) {
 
 }  // namespace
 
-int launch_max_cell(const uint32_t *d_table, size_t nentries, uint32_t *d_out, hipStream_t s) {
-  BIVX_HIP(hipMemsetAsync(d_out, 0, 4, s));
-  if (nentries < 2) return 0;
-  hipLaunchKernelGGL(k_max_cell, dim3(grid_for(nentries, kThreads * 8, 512)), dim3(kThreads), 0, s, d_table, nentries, d_out);
-  BIVX_HIP(hipGetLastError());
-  return 0;
-}
-
 int launch_max_chrom_type(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t *d_out2, hipStream_t s) {
-  BIVX_HIP(hipMemsetAsync(d_out2, 0, 2 * sizeof(uint32_t), s));
-  if (n == 0) return 0;
+  if (n == 0) return 0;  // (the caller has zeroed d_out2)
   hipLaunchKernelGGL(k_max_chrom_type, dim3(grid_for(n, kThreads * 16, 512)), dim3(kThreads), 0, s, d_chrom, d_type, n, d_out2);
   BIVX_HIP(hipGetLastError());
   return 0;
@@ -462,7 +584,7 @@ int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t nt
   const uint32_t nent = nparts * kLenBins;
   hipLaunchKernelGGL(k_init_stats, dim3(grid_for(nent, kThreads)), dim3(kThreads), 0, s, d_stats, nent);
   if (n) {
-    const unsigned nb = grid_for(n, kStatsThreads * 8, 1024);
+    const unsigned nb = grid_for(n, kStatsThreads * kStatsUnroll * 2, 1024);
     if (nent <= kStatsLdsEntries)
       hipLaunchKernelGGL(k_bin_stats<true>, dim3(nb), dim3(kStatsThreads), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
                          nent, d_stats);
@@ -476,18 +598,18 @@ int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t nt
 
 int launch_make_keys(int mode, const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, const uint32_t *d_bin2seg, const uint2 *d_segkey,
-                     const uint32_t *d_ids, uint32_t *d_keys, hipStream_t s) {
+                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, hipStream_t s) {
   if (n == 0) return 0;
   const dim3 grid(grid_for(n, kThreads)), block(kThreads);
   if (mode == kKeyDense)
     hipLaunchKernelGGL(k_make_keys<kKeyDense>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
-                       d_segkey, d_ids, d_keys);
+                       d_segkey, d_ids, d_seg_of, d_keys);
   else if (mode == kKeyLow)
     hipLaunchKernelGGL(k_make_keys<kKeyLow>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
-                       d_segkey, d_ids, d_keys);
+                       d_segkey, d_ids, d_seg_of, d_keys);
   else
     hipLaunchKernelGGL(k_make_keys<kKeySegOfId>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
-                       d_segkey, d_ids, d_keys);
+                       d_segkey, d_ids, d_seg_of, d_keys);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -495,8 +617,7 @@ int launch_make_keys(int mode, const uint32_t *d_chrom, const uint8_t *d_type, u
 size_t radix_scratch_bytes(size_t n) {
   const size_t nblocks = (n + kTile - 1) / kTile;
   const size_t nh = nblocks * kRadix;
-  // histogram + its exclusive scan (+1) + scan scratch
-  return (nh + nh + 1) * sizeof(uint32_t) + 64 + scan_scratch_bytes(nh);
+  return (nh + nh + kRadix) * sizeof(uint32_t);  // histogram, its row-wise exclusive scan, the digits' totals
 }
 
 int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint32_t **vals_alt, size_t n,
@@ -506,18 +627,18 @@ int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint
   const size_t nh = (size_t)nblocks * kRadix;
   uint32_t *hist = static_cast<uint32_t *>(d_scratch);
   uint32_t *offs = hist + nh;
-  void *scan_scr = reinterpret_cast<void *>(((uintptr_t)(offs + nh + 1) + 63) & ~(uintptr_t)63);
+  uint32_t *totals = offs + nh;
   bool iota = vals_are_iota;
   // (at least one pass, so that the values exist in memory when they were only implied)
   for (int shift = 0; shift < nbits || iota; shift += kRadixBits) {
     hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, n, shift, hist, nblocks);
-    BIVX_TRY(exclusive_scan_u32_u32(hist, offs, nh, scan_scr, s));
+    hipLaunchKernelGGL(k_radix_rows, dim3(kRadix), dim3(kThreads), 0, s, hist, offs, totals, nblocks);
     if (iota)
       hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, *vals, *keys_alt,
-                         *vals_alt, n, shift, offs, nblocks);
+                         *vals_alt, n, shift, offs, totals, nblocks);
     else
       hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, *vals, *keys_alt,
-                         *vals_alt, n, shift, offs, nblocks);
+                         *vals_alt, n, shift, offs, totals, nblocks);
     BIVX_HIP(hipGetLastError());
     iota = false;
     uint32_t *t = *keys; *keys = *keys_alt; *keys_alt = t;
@@ -526,27 +647,27 @@ int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint
   return 0;
 }
 
+size_t finalize_gap_capacity(uint64_t nentries, uint32_t nseg) { return (size_t)(nentries / kCoopMax) + 2u * nseg + 64u; }
+size_t finalize_gap_bytes(uint64_t nentries, uint32_t nseg) { return finalize_gap_capacity(nentries, nseg) * sizeof(Gap); }
+
 int launch_finalize(const uint32_t *d_keys, const uint32_t *d_ids, const uint32_t *d_low, const uint32_t *d_high,
-                    const SegDesc *d_seg, const uint2 *d_segkey, uint32_t nseg, uint2 *d_se, uint2 *d_rec, size_t n,
-                    hipStream_t s) {
+                    const SegDesc *d_seg, const uint2 *d_segkey, uint32_t nseg, uint2 *d_se, uint2 *d_rec,
+                    uint32_t *d_table, uint64_t nentries, void *d_gaps, uint32_t *d_ngaps, uint32_t *d_max_cell,
+                    size_t n, hipStream_t s) {
   if (n == 0 || nseg == 0) return 0;
   const uint32_t nchunks = grid_for(n, kThreads);
   const unsigned grid = ((nchunks + 7u) / 8u) * 8u;
+  const uint32_t cap = (uint32_t)finalize_gap_capacity(nentries, nseg);
+  Gap *gaps = static_cast<Gap *>(d_gaps);
   if (d_keys)
     hipLaunchKernelGGL(k_finalize<true>, dim3(grid), dim3(kThreads), 0, s, d_keys, d_ids, d_low, d_high, d_seg, d_segkey, nseg,
-                       d_se, d_rec, n, nchunks);
+                       d_se, d_rec, d_table, gaps, d_ngaps, cap, n, nchunks);
   else
     hipLaunchKernelGGL(k_finalize<false>, dim3(grid), dim3(kThreads), 0, s, d_keys, d_ids, d_low, d_high, d_seg, d_segkey,
-                       nseg, d_se, d_rec, n, nchunks);
-  BIVX_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_build_table(const uint2 *d_se, const SegDesc *d_seg, uint32_t nseg, uint32_t *d_table,
-                       uint64_t nentries, hipStream_t s) {
-  if (nentries == 0) return 0;
-  hipLaunchKernelGGL(k_build_table, dim3(grid_for(nentries, kThreads)), dim3(kThreads), 0, s, d_se, d_seg, nseg,
-                     d_table, nentries);
+                       nseg, d_se, d_rec, d_table, gaps, d_ngaps, cap, n, nchunks);
+  hipLaunchKernelGGL(k_fill_gaps, dim3(256), dim3(kThreads), 0, s, gaps, d_ngaps, cap, d_table);
+  hipLaunchKernelGGL(k_max_cell, dim3(grid_for(nentries, kThreads * 8, 512)), dim3(kThreads), 0, s, d_table, (size_t)nentries,
+                     d_max_cell);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

@@ -51,7 +51,8 @@ struct bivx_index {
   };
   DevBuf b_se, b_rec, b_table, b_seg, b_rng;  // what the pointers below point into
   DevBuf b_keys[2], b_ids[2];                 // sort buffers; the ids end up in one of b_ids and stay there (d_id)
-  DevBuf b_misc, b_radix;                     // build temporaries: statistics, key tables, histogram scratch
+  DevBuf b_misc, b_radix, b_scalar, b_segof;  // build temporaries: statistics, key tables, histogram scratch, maxima,
+                                              // every interval's segment (two-sort builds)
   uint32_t *h_scalars = nullptr;              // pinned: the build's few read-backs (max ids, largest cell)
   // bivx_append_dev copies on the CALLER's stream; the build waits for those copies on its own stream through events
   // instead of synchronising the device
@@ -209,7 +210,7 @@ void free_built(bivx_index *idx) {
 
 void release_build_blocks(bivx_index *idx) {
   for (bivx_index::DevBuf *b : {&idx->b_se, &idx->b_rec, &idx->b_table, &idx->b_seg, &idx->b_rng, &idx->b_keys[0],
-                                &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix}) {
+                                &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof}) {
     (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
@@ -711,10 +712,11 @@ int bivx_build(bivx_index *idx) {
   // partitioned by (chromosome, svtype) — the "virtual chromosome" chrom * ntypes + svtype takes the chromosome's place
   // in everything below, so a query that asks for one type walks only that type's segments and pays nothing per
   // candidate (the svtype filter of mapper.hpp:153-156, done by the layout instead of by three trees)
-  BIVX_TRY(ensure_block(idx->b_misc, 256));
-  uint32_t *d_scalar = static_cast<uint32_t *>(idx->b_misc.p);  // [0] max chromosome, [1] max svtype, [2] largest cell
+  BIVX_TRY(ensure_block(idx->b_scalar, 256));
+  uint32_t *d_scalar = static_cast<uint32_t *>(idx->b_scalar.p);  // [0] max chromosome, [1] max svtype, [2] largest cell
   uint32_t max_chrom = 0, max_type = 0;
   if (n) {
+    BIVX_HIP(hipMemsetAsync(d_scalar, 0, 16, s));  // the three maxima start at zero
     BIVX_TRY(launch_max_chrom_type(idx->d_chrom, idx->typed ? idx->d_type : nullptr, n, d_scalar, s));
     BIVX_HIP(hipMemcpyAsync(idx->h_scalars, d_scalar, 8, hipMemcpyDeviceToHost, s));
     BIVX_HIP(hipStreamSynchronize(s));
@@ -740,9 +742,8 @@ int bivx_build(bivx_index *idx) {
   const size_t stats_bytes = (st.size() * sizeof(BinStats) + 255) & ~(size_t)255;
   const size_t b2s_bytes = (st.size() * 4 + 255) & ~(size_t)255;
   if (n) {
-    BIVX_TRY(ensure_block(idx->b_misc, 256 + stats_bytes + b2s_bytes));
-    d_scalar = static_cast<uint32_t *>(idx->b_misc.p);
-    BinStats *d_stats = reinterpret_cast<BinStats *>(static_cast<char *>(idx->b_misc.p) + 256);
+    BIVX_TRY(ensure_block(idx->b_misc, stats_bytes + b2s_bytes));
+    BinStats *d_stats = static_cast<BinStats *>(idx->b_misc.p);
     BIVX_TRY(launch_bin_stats(idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, nvchrom, d_stats, s));
     BIVX_HIP(hipMemcpyAsync(st.data(), d_stats, st.size() * sizeof(BinStats), hipMemcpyDeviceToHost, s));
     BIVX_HIP(hipStreamSynchronize(s));
@@ -786,23 +787,27 @@ int bivx_build(bivx_index *idx) {
       BIVX_TRY(ensure_block(idx->b_keys[k], n * 4));
       BIVX_TRY(ensure_block(idx->b_ids[k], n * 4));
     }
-    BIVX_TRY(ensure_block(idx->b_radix, radix_scratch_bytes(n)));
+    // (histogram scratch of the sort, then the directory pass's short list of long empty stretches)
+    BIVX_TRY(ensure_block(idx->b_radix, std::max(radix_scratch_bytes(n), finalize_gap_bytes(plan.nentries, nseg))));
     uint32_t *kA = static_cast<uint32_t *>(idx->b_keys[0].p), *kB = static_cast<uint32_t *>(idx->b_keys[1].p);
     uint32_t *vA = static_cast<uint32_t *>(idx->b_ids[0].p), *vB = static_cast<uint32_t *>(idx->b_ids[1].p);
-    uint32_t *d_bin2seg = reinterpret_cast<uint32_t *>(static_cast<char *>(idx->b_misc.p) + 256 + stats_bytes);
+    uint32_t *d_bin2seg = reinterpret_cast<uint32_t *>(static_cast<char *>(idx->b_misc.p) + stats_bytes);
     BIVX_HIP(hipMemcpyAsync(d_bin2seg, plan.bin2seg.data(), plan.bin2seg.size() * 4, hipMemcpyHostToDevice, s));
     const bool dense = plan.key_span <= 0xFFFFFFFFull && !std::getenv("BIVX_BUILD_TWO_STAGE");  // (env: test knob)
     if (dense) {
       BIVX_TRY(launch_make_keys(kBuildKeyDense, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
-                                nullptr, kA, s));
+                                nullptr, nullptr, kA, s));
       BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for((uint32_t)(plan.key_span - 1)), idx->b_radix.p, true, s));
     } else {
+      // (every interval's segment, in append order: the second sort's keys are one gather of it)
+      BIVX_TRY(ensure_block(idx->b_segof, n * 4));
+      uint32_t *d_seg_of = static_cast<uint32_t *>(idx->b_segof.p);
       BIVX_TRY(launch_make_keys(kBuildKeyLow, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
-                                nullptr, kA, s));
+                                nullptr, d_seg_of, kA, s));
       BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), idx->b_radix.p, true, s));
       if (nseg > 1) {
         BIVX_TRY(launch_make_keys(kBuildKeySegOfId, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg,
-                                  d_segkey, vA, kA, s));
+                                  d_segkey, vA, d_seg_of, kA, s));
         BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), idx->b_radix.p, false, s));
       }
     }
@@ -814,16 +819,11 @@ int bivx_build(bivx_index *idx) {
     BIVX_TRY(ensure_block(idx->b_rec, (n + 2) * sizeof(uint2)));
     idx->d_se = static_cast<uint2 *>(idx->b_se.p);
     idx->d_rec = static_cast<uint2 *>(idx->b_rec.p);
-    BIVX_HIP(hipMemsetAsync(idx->d_se + n, 0xFF, 2 * sizeof(uint2), s));
-    BIVX_HIP(hipMemsetAsync(idx->d_rec + n, 0, 2 * sizeof(uint2), s));
-    BIVX_TRY(launch_finalize(dense ? kA : nullptr, idx->d_id, idx->d_low, idx->d_high, idx->d_seg, d_segkey, nseg, idx->d_se,
-                             idx->d_rec, n, s));
-    // 6. bucket directory (+3 spare entries: query lanes read directory entries four at a time)
+    // 6. ... and the bucket directory, by the same pass (+3 spare entries: query lanes read entries four at a time)
     BIVX_TRY(ensure_block(idx->b_table, ((size_t)plan.nentries + 3) * 4));
     idx->d_table = static_cast<uint32_t *>(idx->b_table.p);
-    BIVX_HIP(hipMemsetAsync(idx->d_table + plan.nentries, 0xFF, 3 * 4, s));
-    BIVX_TRY(launch_build_table(idx->d_se, idx->d_seg, nseg, idx->d_table, plan.nentries, s));
-    BIVX_TRY(launch_max_cell(idx->d_table, plan.nentries, d_scalar + 2, s));
+    BIVX_TRY(launch_finalize(dense ? kA : nullptr, idx->d_id, idx->d_low, idx->d_high, idx->d_seg, d_segkey, nseg, idx->d_se,
+                             idx->d_rec, idx->d_table, plan.nentries, idx->b_radix.p, d_scalar + 3, d_scalar + 2, n, s));
     BIVX_HIP(hipMemcpyAsync(idx->h_scalars + 2, d_scalar + 2, 4, hipMemcpyDeviceToHost, s));
   }
   BIVX_HIP(hipStreamSynchronize(s));

@@ -111,40 +111,35 @@ int sharded_any(const ShardedState *st, const uint32_t *qchrom, const uint32_t *
                 size_t q, uint32_t *first_id_out);
 void sharded_stats(const ShardedState *st, bivx_stats *out);
 
-// ---- scan.hip ---------------------------------------------------------------------------------------
-// out[0..n] = exclusive prefix sums of in[0..n), out[n] = total. scratch: scan_scratch_bytes(n).
-size_t scan_scratch_bytes(size_t n);
-int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s);
-int exclusive_scan_u32_u32(const uint32_t *d_in, uint32_t *d_out, size_t n, void *d_scratch, hipStream_t s);
-
 // ---- build.hip --------------------------------------------------------------------------------------
 // the partition of interval i is chrom[i] * ntypes + type[i] (type == nullptr: chrom[i])
 int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, uint32_t nparts, BinStats *d_stats, hipStream_t s);
-// d_out2[0] = max chromosome id, d_out2[1] = max svtype (d_type may be nullptr)
+// d_out2[0] = max chromosome id, d_out2[1] = max svtype (d_type may be nullptr); atomic maxima into words the caller zeroed
 int launch_max_chrom_type(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t *d_out2, hipStream_t s);
-int launch_max_cell(const uint32_t *d_table, size_t nentries, uint32_t *d_out, hipStream_t s);
 // out[i] = src ? src[ids[i]] : 0 for ids[i] < n_src, else 0xFF
 int launch_gather_u8(const uint8_t *d_src, const uint32_t *d_ids, size_t n, size_t n_src, uint8_t *d_out,
                      hipStream_t s);
 // sort keys. mode 0 (dense): keys[i] = segkey[seg(i)].x + (low[i] - segkey[seg(i)].y) — (segment, low) in one word;
-// mode 1: keys[i] = low[i]; mode 2: keys[i] = seg(ids[i]) (second stage of the two-stage sort)
+// mode 1: keys[i] = low[i] and d_seg_of[i] = seg(i); mode 2: keys[i] = d_seg_of[ids[i]] (second stage of the two-stage sort)
 enum : int { kBuildKeyDense = 0, kBuildKeyLow = 1, kBuildKeySegOfId = 2 };
 int launch_make_keys(int mode, const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, const uint32_t *d_bin2seg, const uint2 *d_segkey,
-                     const uint32_t *d_ids, uint32_t *d_keys, hipStream_t s);
+                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, hipStream_t s);
 // stable LSD radix sort of (key, val) pairs on key bits [0, nbits); result ends in (*keys, *vals)
 // (the pointers are swapped with the alt buffers as passes ping-pong). scratch: radix_scratch_bytes(n).
 // vals_are_iota: the values are 0 .. n-1 and need not exist in memory yet (the first pass writes them).
 size_t radix_scratch_bytes(size_t n);
 int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint32_t **vals_alt, size_t n,
                      int nbits, void *d_scratch, bool vals_are_iota, hipStream_t s);
-// se[] and rec[] from the sorted ids (and the sorted dense keys; d_keys == nullptr: low is gathered by id)
+// se[], rec[] and the bucket directory (with its three spare entries) from the sorted ids (and the sorted dense keys;
+// d_keys == nullptr: low is gathered by id). d_gaps: finalize_gap_bytes() of scratch; *d_ngaps and *d_max_cell must be
+// zero; *d_max_cell receives the largest number of slots any directory cell holds.
+size_t finalize_gap_bytes(uint64_t nentries, uint32_t nseg);
 int launch_finalize(const uint32_t *d_keys, const uint32_t *d_ids, const uint32_t *d_low, const uint32_t *d_high,
-                    const SegDesc *d_seg, const uint2 *d_segkey, uint32_t nseg, uint2 *d_se, uint2 *d_rec, size_t n,
-                    hipStream_t s);
-int launch_build_table(const uint2 *d_se, const SegDesc *d_seg, uint32_t nseg, uint32_t *d_table,
-                       uint64_t ncells_total, hipStream_t s);
+                    const SegDesc *d_seg, const uint2 *d_segkey, uint32_t nseg, uint2 *d_se, uint2 *d_rec,
+                    uint32_t *d_table, uint64_t nentries, void *d_gaps, uint32_t *d_ngaps, uint32_t *d_max_cell,
+                    size_t n, hipStream_t s);
 int launch_gather_intervals(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
                             const uint32_t *d_ids, size_t n, size_t n_intervals, uint32_t *d_c, uint32_t *d_l,
                             uint32_t *d_h, hipStream_t s);

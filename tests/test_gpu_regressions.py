@@ -144,3 +144,91 @@ def test_mailbox_capacity_edge_and_fallback(extra):
             off, hits = idx.find_overlaps(qlo, qlo, qc, sort_by_id=ordered)
             assert int(off[-1]) == 7870 + extra
             _check_csr(off, hits, _brute(chrom, low, high, np.ones(K + 1, bool), qc, qlo, qlo), ordered)
+
+
+# ---- round 3 build: one dense (segment, low) sort key, or two stable sorts when no 32-bit key exists ----------------
+
+def _index_order_csr(idx, qlo, qhi, qc):
+    off, hits = idx.find_overlaps(qlo, qhi, qc, sort_by_id=False)
+    return off.copy(), np.array(hits, copy=True)
+
+
+def test_build_two_stage_sort_equals_dense_key_sort(monkeypatch):
+    """The same intervals built both ways give the same index: same CSR in INDEX order, bit for bit (index order is
+    (length class, low, id): it exposes the sorted arrays themselves)."""
+    from binary_amd import IntervalIndex
+    chrom, low, high, typ = _typed_multiclass_index(9)
+    low[::7] = low[7]                                   # many equal lows: ties must keep append order
+    high = np.maximum(high, low).astype(np.uint32)
+    rng = np.random.default_rng(1)
+    q = 30_000
+    qc = rng.integers(0, 3, q).astype(np.uint32)
+    qlo = rng.integers(0, 1_000_000, q).astype(np.uint32)
+    qhi = (qlo + rng.integers(0, 2000, q)).astype(np.uint32)
+    res = []
+    for two_stage in (False, True):
+        if two_stage:
+            monkeypatch.setenv("BIVX_BUILD_TWO_STAGE", "1")
+        with IntervalIndex(0) as idx:
+            idx.insert_node(low, high, chrom, svtype=typ)
+            idx.build()
+            res.append(_index_order_csr(idx, qlo, qhi, qc))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    exp = _brute(chrom, low, high, np.ones(low.size, bool), qc[:300], qlo[:300], qhi[:300])
+    for k, e in enumerate(exp):
+        assert np.array_equal(np.sort(res[0][1][int(res[0][0][k]):int(res[0][0][k + 1])].astype(np.int64)), e)
+
+
+def test_build_coordinate_spans_beyond_32_bits():
+    """Three chromosomes whose lows each span the whole uint32 range: the segments' spans add up to 3 x 2^32, no 32-bit
+    (segment, low) key exists and the build takes the two-sort route by itself. Includes low > high entries, the
+    extremes 0 and 2^32 - 1, and a rebuild after a second append (pooled device blocks are reused)."""
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(12)
+    n = 30_000
+    chrom = rng.integers(0, 3, n).astype(np.uint32)
+    low = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    high = np.minimum(low.astype(np.uint64) + rng.integers(0, 1 << 22, n, dtype=np.uint64), 0xFFFFFFFF).astype(np.uint32)
+    inv = rng.random(n) < 0.1
+    low[inv], high[inv] = high[inv], low[inv]
+    low[:3], high[:3] = 0, 0
+    low[3:6], high[3:6] = 0xFFFFFFFF, 0xFFFFFFFF
+    q = 400
+    qc = rng.integers(0, 3, q).astype(np.uint32)
+    qlo = rng.integers(0, 1 << 32, q, dtype=np.uint64).astype(np.uint32)
+    qhi = np.minimum(qlo.astype(np.uint64) + rng.integers(0, 1 << 24, q, dtype=np.uint64), 0xFFFFFFFF).astype(np.uint32)
+    qlo[0], qhi[0] = 0, 0
+    qlo[1], qhi[1] = 0xFFFFFFFF, 0xFFFFFFFF
+    qlo[2], qhi[2] = 0, 0xFFFFFFFF
+    with IntervalIndex(0) as idx:
+        half = n // 2
+        idx.insert_node(low[:half], high[:half], chrom[:half])
+        idx.build()
+        off, hits = idx.find_overlaps(qlo, qhi, qc)
+        _check_csr(off, hits, _brute(chrom[:half], low[:half], high[:half], np.ones(half, bool), qc, qlo, qhi), True)
+        idx.insert_node(low[half:], high[half:], chrom[half:])
+        idx.build()
+        off, hits = idx.find_overlaps(qlo, qhi, qc)
+        _check_csr(off, hits, _brute(chrom, low, high, np.ones(n, bool), qc, qlo, qhi), True)
+        first = idx.find_overlap(qlo, qhi, qc)
+        exp = _brute(chrom, low, high, np.ones(n, bool), qc, qlo, qhi)
+        assert np.array_equal(first, np.array([e[0] if e.size else 0xFFFFFFFF for e in exp], np.uint32))
+
+
+def test_directory_with_long_empty_stretches_and_one_crowded_cell():
+    """The directory entries are found by interpolation + bracketing: clustered lows are where a uniform guess is far
+    off. Two clusters at the ends of a 200 Mbp chromosome, 60 000 intervals starting at ONE coordinate, a lone interval."""
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(3)
+    low = np.r_[rng.integers(0, 5000, 20_000), rng.integers(199_990_000, 200_000_000, 20_000),
+                np.full(60_000, 77_777_777), [123_456_789]].astype(np.uint32)
+    high = (low + rng.integers(0, 300, low.size)).astype(np.uint32)
+    chrom = np.zeros(low.size, np.uint32)
+    qlo = np.r_[rng.integers(0, 6000, 500), rng.integers(199_989_000, 200_000_100, 500), [77_777_700, 77_777_777, 77_778_200,
+                123_456_700, 123_457_100, 50_000_000]].astype(np.uint32)
+    qhi = (qlo + rng.integers(0, 400, qlo.size)).astype(np.uint32)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        off, hits = idx.find_overlaps(qlo, qhi)
+        _check_csr(off, hits, _brute(chrom, low, high, np.ones(low.size, bool), np.zeros(qlo.size, np.uint32), qlo, qhi), True)
