@@ -7,7 +7,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libbivx.so")
-_SOURCES = ("build.hip", "query.hip", "query_fused.hip", "query_pipe.hip", "prefix_device.h", "query_device.h", "wave_device.h", "capi.hip", "sharded.cpp", "common.h",
+_SOURCES = ("scan.hip", "build.hip", "query.hip", "query_fused.hip", "query_pipe.hip", "prefix_device.h", "query_device.h", "wave_device.h", "capi.hip", "sharded.cpp", "common.h",
             "Makefile")
 
 

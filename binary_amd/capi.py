@@ -11,7 +11,7 @@ from ._build import LIB_PATH
 
 BIVX_NO_HIT = 0xFFFFFFFF
 E_INVALID, E_HIP, E_NOMEM, E_STATE, E_RANGE, E_TIMEOUT = -1, -2, -3, -4, -5, -6
-ABI_VERSION = 0x00020000
+ABI_VERSION = 0x00020001
 
 EXPORTS = (
     "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_create_sharded", "bivx_num_devices", "bivx_device_of_chrom", "bivx_destroy", "bivx_device", "bivx_append",
@@ -19,7 +19,7 @@ EXPORTS = (
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
     "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f", "bivx_query_dev_s", "bivx_query_dev_u",
-    "bivx_find_overlaps", "bivx_free", "bivx_stream_status", "bivx_query_kernel_name", "bivx_debug_corrupt_workspace",
+    "bivx_find_overlaps", "bivx_free", "bivx_self_overlaps_dev", "bivx_stream_status", "bivx_query_kernel_name", "bivx_debug_corrupt_workspace",
 )
 
 
@@ -106,6 +106,7 @@ def load() -> C.CDLL:
     L.bivx_fill_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, vp]
     L.bivx_query_dev_f.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, C.c_uint64, vp, sz, vp]
     L.bivx_query_dev_s.argtypes = [vp, u32p, u32p, u32p, sz, fp, C.c_int, u64p, u32p, C.c_uint64, vp, sz, vp]
+    L.bivx_self_overlaps_dev.argtypes = [vp, C.c_int, u64p, u32p, C.c_uint64, vp]
     L.bivx_query_dev_u.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, u32p, C.c_uint64, u64p, vp, sz, vp]
     if L.bivx_abi_version() >> 16 != ABI_VERSION >> 16:
         raise ImportError("libbivx.so ABI major version mismatch")

@@ -555,6 +555,25 @@ __global__ __launch_bounds__(kThreads) void k_max_cell(uint32_t *__restrict__ ta
   block_max_to(m, out);
 }
 
+// The index's own intervals as a batch of queries in slot order (bivx_self_overlaps_dev): (chromosome of the slot's
+// segment, low, high) — position-sorted by construction.
+__global__ __launch_bounds__(kThreads) void k_self_queries(const uint2 *__restrict__ se, const SegDesc *__restrict__ seg,
+                                                           const uint32_t *__restrict__ seg_chrom, uint32_t nseg, size_t n,
+                                                           uint32_t *__restrict__ qchrom, uint32_t *__restrict__ qlow,
+                                                           uint32_t *__restrict__ qhigh) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = nseg;  // last segment with begin <= i
+  while (hi - lo > 1) {
+    const uint32_t m = (lo + hi) >> 1;
+    if ((size_t)seg[m].begin <= i) lo = m; else hi = m;
+  }
+  const uint2 e = se[i];
+  qchrom[i] = seg_chrom[lo];
+  qlow[i] = e.x;
+  qhigh[i] = e.y;
+}
+
 inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0) {
   size_t nb = (n + (size_t)per_block - 1) / (size_t)per_block;
   if (nb < 1) nb = 1;
@@ -668,6 +687,15 @@ int launch_finalize(const uint32_t *d_keys, const uint32_t *d_ids, const uint32_
   hipLaunchKernelGGL(k_fill_gaps, dim3(256), dim3(kThreads), 0, s, gaps, d_ngaps, cap, d_table);
   hipLaunchKernelGGL(k_max_cell, dim3(grid_for(nentries, kThreads * 8, 512)), dim3(kThreads), 0, s, d_table, (size_t)nentries,
                      d_max_cell);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_self_queries(const uint2 *d_se, const SegDesc *d_seg, const uint32_t *d_seg_chrom, uint32_t nseg, size_t n,
+                        uint32_t *d_qchrom, uint32_t *d_qlow, uint32_t *d_qhigh, hipStream_t s) {
+  if (n == 0 || nseg == 0) return 0;
+  hipLaunchKernelGGL(k_self_queries, dim3(grid_for(n, kThreads)), dim3(kThreads), 0, s, d_se, d_seg, d_seg_chrom, nseg, n,
+                     d_qchrom, d_qlow, d_qhigh);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

@@ -57,6 +57,12 @@ struct bivx_index {
   // bivx_append_dev copies on the CALLER's stream; the build waits for those copies on its own stream through events
   // instead of synchronising the device
   std::vector<hipEvent_t> ev_pending, ev_free;
+  // the built index's own intervals as a query batch in slot order (chromosome, low, high), made by the first
+  // bivx_self_overlaps_dev call after a build
+  mutable DevBuf b_selfq;
+  mutable bool selfq_valid = false;
+  mutable std::mutex self_mutex;
+  uint32_t *d_seg_chrom = nullptr;     // chromosome of every segment (behind the descriptors' sort keys in b_seg)
   bool built = false;
   uint2 *d_se = nullptr;
   uint2 *d_rec = nullptr;
@@ -75,6 +81,8 @@ struct bivx_index {
   struct Workspace {
     void *p = nullptr;
     bool needs_reset = false;  // a reported error may have left protocol state behind: cleared before the next launch
+    void *self_p = nullptr;    // bivx_self_overlaps_dev's counts and scan scratch on this stream
+    size_t self_cap = 0;
   };
   mutable std::mutex ws_mutex;
   mutable std::unordered_map<hipStream_t, Workspace> ws_of_stream;
@@ -206,11 +214,12 @@ void free_built(bivx_index *idx) {
   idx->max_segs.clear();
   idx->nentries = 0;
   idx->built = false;
+  idx->selfq_valid = false;
 }
 
 void release_build_blocks(bivx_index *idx) {
   for (bivx_index::DevBuf *b : {&idx->b_se, &idx->b_rec, &idx->b_table, &idx->b_seg, &idx->b_rng, &idx->b_keys[0],
-                                &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof}) {
+                                &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof, &idx->b_selfq}) {
     (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
@@ -615,7 +624,10 @@ void bivx_destroy(bivx_index *idx) {
   DeviceGuard g(idx->device);
   if (idx->stream) (void)hipStreamSynchronize(idx->stream);
   (void)hipDeviceSynchronize();
-  for (auto &kv : idx->ws_of_stream) (void)hipFree(kv.second.p);
+  for (auto &kv : idx->ws_of_stream) {
+    (void)hipFree(kv.second.p);
+    (void)hipFree(kv.second.self_p);
+  }
   if (idx->h_err) (void)hipHostFree(idx->h_err);
   for (auto &m : idx->mailboxes) (void)hipHostFree(m.first);
   idx->mailboxes.clear();
@@ -768,14 +780,20 @@ int bivx_build(bivx_index *idx) {
   // (descriptors and their sort keys in one block: [SegDesc x nseg | (keybase, base) x nseg])
   const size_t seg_bytes = ((size_t)(nseg ? nseg : 1) * sizeof(SegDesc) + 255) & ~(size_t)255;
   BIVX_TRY(ensure_block(idx->b_rng, rng.size() * sizeof(uint2)));
-  BIVX_TRY(ensure_block(idx->b_seg, seg_bytes + (size_t)(nseg ? nseg : 1) * sizeof(uint2)));
+  // ([SegDesc | (keybase, base) | chromosome] x nseg)
+  BIVX_TRY(ensure_block(idx->b_seg, seg_bytes + (size_t)(nseg ? nseg : 1) * (sizeof(uint2) + sizeof(uint32_t))));
   idx->d_chrom_rng = static_cast<uint2 *>(idx->b_rng.p);
   idx->d_seg = static_cast<SegDesc *>(idx->b_seg.p);
   uint2 *d_segkey = reinterpret_cast<uint2 *>(static_cast<char *>(idx->b_seg.p) + seg_bytes);
+  idx->d_seg_chrom = reinterpret_cast<uint32_t *>(d_segkey + (nseg ? nseg : 1));
+  std::vector<uint32_t> seg_chrom(nseg);
+  for (uint32_t c = 0; c < nvchrom; ++c)
+    for (uint32_t k = plan.chrom_seg[c]; k < plan.chrom_seg[c + 1]; ++k) seg_chrom[k] = c / ntypes;
   BIVX_HIP(hipMemcpyAsync(idx->d_chrom_rng, rng.data(), rng.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
   if (nseg) {
     BIVX_HIP(hipMemcpyAsync(idx->d_seg, plan.segs.data(), (size_t)nseg * sizeof(SegDesc), hipMemcpyHostToDevice, s));
     BIVX_HIP(hipMemcpyAsync(d_segkey, plan.segkey.data(), (size_t)nseg * sizeof(uint2), hipMemcpyHostToDevice, s));
+    BIVX_HIP(hipMemcpyAsync(idx->d_seg_chrom, seg_chrom.data(), (size_t)nseg * sizeof(uint32_t), hipMemcpyHostToDevice, s));
   }
 
   uint32_t max_cell = 0;
@@ -1021,6 +1039,93 @@ int bivx_query_dev_u(const bivx_index *idx, const uint32_t *d_qchrom, const uint
   uint32_t dummy = 0;
   return query_single_pass(idx, d_qchrom, d_qlow, d_qhigh, q, filter, 0, d_begin, q ? d_count : &dummy, d_hit_ids,
                            hit_capacity, d_total, d_workspace, workspace_bytes, stream, "bivx_query_dev_u");
+}
+
+int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_offsets, uint32_t *d_hit_ids,
+                           uint64_t hit_capacity, void *stream) {
+  if (!idx || !d_offsets || (hit_capacity && !d_hit_ids)) {
+    set_error("bivx_self_overlaps_dev: null argument");
+    return BIVX_E_INVALID;
+  }
+  BIVX_NOT_SHARDED(idx, "bivx_self_overlaps_dev");
+  if (!idx->built || idx->built_n != idx->n) {
+    set_error("bivx_self_overlaps_dev: index not built (call bivx_build after the last append)");
+    return BIVX_E_STATE;
+  }
+  const size_t n = idx->built_n;
+  const IndexView view = view_of(idx);
+  if (n == 0 || !self_overlaps_eligible(view, n))  // the general path: the appended columns are the batch
+    return query_single_pass(idx, idx->d_chrom, idx->d_low, idx->d_high, n, nullptr, sort_by_id, d_offsets, nullptr,
+                             d_hit_ids, hit_capacity, nullptr, nullptr, 0, stream, "bivx_self_overlaps_dev");
+  BIVX_GUARD(idx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // the intervals as queries in slot order, once per build (on the index's stream, finished before anybody uses them)
+  {
+    std::lock_guard<std::mutex> lock(idx->self_mutex);
+    if (!idx->selfq_valid) {
+      BIVX_TRY(ensure_block(idx->b_selfq, n * 12));
+      uint32_t *q = static_cast<uint32_t *>(idx->b_selfq.p);
+      BIVX_TRY(launch_self_queries(idx->d_se, idx->d_seg, idx->d_seg_chrom, idx->nseg, n, q, q + n, q + 2 * n, idx->stream));
+      BIVX_HIP(hipStreamSynchronize(idx->stream));
+      idx->selfq_valid = true;
+    }
+  }
+  const uint32_t *q = static_cast<const uint32_t *>(idx->b_selfq.p);
+  void *ws = nullptr, *self_p = nullptr;
+  // per stream: [counts u32 x n | scan scratch | list sources u64 x n | the lists in slot order u32 x capacity]
+  const size_t cnt_bytes = (n * 4 + 255) & ~(size_t)255, scan_bytes = (scan_scratch_bytes(n) + 255) & ~(size_t)255;
+  const size_t src_bytes = hit_capacity ? (n * 8 + 255) & ~(size_t)255 : 0;
+  const size_t self_bytes = cnt_bytes + scan_bytes + src_bytes + (size_t)hit_capacity * 4;
+  {
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    auto it = idx->ws_of_stream.find(s);
+    const bool fresh = it == idx->ws_of_stream.end();
+    if (fresh || it->second.needs_reset || it->second.self_cap < self_bytes) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        set_error("bivx_self_overlaps_dev: the first call on a stream allocates the index's workspaces and cannot be "
+                  "captured: make one call on this stream before the capture");
+        return BIVX_E_STATE;
+      }
+      if (fresh) {
+        void *p = nullptr;
+        BIVX_HIP(hipMalloc(&p, fused_workspace_bytes(n)));
+        bivx_index::Workspace w;
+        w.p = p;
+        w.needs_reset = true;
+        it = idx->ws_of_stream.emplace(s, w).first;
+      }
+      if (it->second.needs_reset) {
+        BIVX_HIP(hipMemsetAsync(it->second.p, 0, fused_workspace_bytes(n), s));
+        it->second.needs_reset = false;
+      }
+      if (it->second.self_cap < self_bytes) {
+        BIVX_HIP(hipStreamSynchronize(s));  // (an earlier call on this stream may still use the old block)
+        (void)hipFree(it->second.self_p);
+        it->second.self_p = nullptr;
+        it->second.self_cap = 0;
+        BIVX_HIP(hipMalloc(&it->second.self_p, self_bytes));
+        it->second.self_cap = self_bytes;
+      }
+    }
+    ws = it->second.p;
+    self_p = it->second.self_p;
+  }
+  char *base = static_cast<char *>(self_p);
+  uint32_t *d_counts = reinterpret_cast<uint32_t *>(base);
+  void *scan_scr = base + cnt_bytes;
+  uint64_t *d_src = reinterpret_cast<uint64_t *>(base + cnt_bytes + scan_bytes);
+  uint32_t *d_tmp = reinterpret_cast<uint32_t *>(base + cnt_bytes + scan_bytes + src_bytes);
+  // one pass in slot order (lists back to back in d_tmp; per id the list's length and where it begins), offsets = a scan of
+  // the lengths, then the lists are gathered into id order
+  BIVX_TRY(launch_self_overlaps(view, q, q + n, q + 2 * n, idx->d_id, n, d_counts, hit_capacity ? d_src : nullptr, d_offsets,
+                                hit_capacity ? d_tmp : nullptr, hit_capacity, static_cast<uint64_t *>(ws), true, s));
+  BIVX_TRY(exclusive_scan_u32_u64(d_counts, d_offsets, n, scan_scr, s));
+  if (hit_capacity) {
+    BIVX_TRY(launch_permute_lists(d_offsets, d_src, d_tmp, d_hit_ids, n, hit_capacity, s));
+    if (sort_by_id) BIVX_TRY(launch_sort_hits(d_offsets, d_hit_ids, n, hit_capacity, s));
+  }
+  return 0;
 }
 
 int bivx_stream_status(const bivx_index *idx, void *stream) {

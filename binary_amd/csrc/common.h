@@ -111,6 +111,11 @@ int sharded_any(const ShardedState *st, const uint32_t *qchrom, const uint32_t *
                 size_t q, uint32_t *first_id_out);
 void sharded_stats(const ShardedState *st, bivx_stats *out);
 
+// ---- scan.hip ---------------------------------------------------------------------------------------
+// out[0..n] = exclusive prefix sums of in[0..n), out[n] = total. scratch: scan_scratch_bytes(n).
+size_t scan_scratch_bytes(size_t n);
+int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s);
+
 // ---- build.hip --------------------------------------------------------------------------------------
 // the partition of interval i is chrom[i] * ntypes + type[i] (type == nullptr: chrom[i])
 int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
@@ -143,6 +148,9 @@ int launch_finalize(const uint32_t *d_keys, const uint32_t *d_ids, const uint32_
 int launch_gather_intervals(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high,
                             const uint32_t *d_ids, size_t n, size_t n_intervals, uint32_t *d_c, uint32_t *d_l,
                             uint32_t *d_h, hipStream_t s);
+// the built index's intervals as queries in slot order: (chromosome of the slot's segment, low, high)
+int launch_self_queries(const uint2 *d_se, const SegDesc *d_seg, const uint32_t *d_seg_chrom, uint32_t nseg, size_t n,
+                        uint32_t *d_qchrom, uint32_t *d_qlow, uint32_t *d_qhigh, hipStream_t s);
 
 // ---- query.hip, query_fused.hip ---------------------------------------------------------------------------
 int launch_query_tiny(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
@@ -168,6 +176,16 @@ bool pipe_dense_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_i
 int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                             size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
                             int flags, uint32_t seq, hipStream_t s);
+// The index overlapped with itself (queries = its intervals in slot order, results wanted in id order: d_perm = the slots'
+// ids): k_query_pipe_dense writes the lists in slot order into d_tmp_hits and leaves d_counts[id] / d_src_by_id[id] = a
+// list's length / where it begins (cap == 0: the lengths only); launch_permute_lists then gathers list i to d_hits[offsets[i]].
+bool self_overlaps_eligible(const IndexView &v, size_t n);
+int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                         const uint32_t *d_perm, size_t n, uint32_t *d_counts, uint64_t *d_src_by_id,
+                         uint64_t *d_offsets_scratch, uint32_t *d_tmp_hits, uint64_t cap, uint64_t *ws, bool self_clean,
+                         hipStream_t s);
+int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
+                         uint64_t cap, hipStream_t s);
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
                       int flags, uint32_t sort_seq, uint32_t *d_counts, uint64_t *d_total, hipStream_t s);

@@ -76,7 +76,16 @@ struct PipeArgs {
   // `counts` its number of ids and `total_out` the batch's total
   uint32_t *counts;
   uint64_t *total_out;
+  // Results wanted in ANOTHER order than the queries' (bivx_self_overlaps_dev: the queries are the index's own intervals
+  // in slot order, the CSR is wanted in id order; k_query_pipe_dense and k_fill_slices only). perm[q] = the query's
+  // position in the result. The ids are written as always — the batch's lists back to back, in the queries' order — but
+  // instead of offsets[q] the kernel leaves dst_counts[perm[q]] = the query's number of ids and src_by_id[perm[q]] = where
+  // its list begins; k_permute_lists then moves the lists into the result's order.
+  const uint32_t *perm;
+  uint64_t *src_by_id;
+  uint32_t *dst_counts;
 };
+constexpr int kFlagSorted = 4;  // k_query_pipe_dense: the batch is known to be position-sorted (no order probe was launched)
 
 // The kernel's arguments stay where the launch put them — the kernarg segment, constant memory — and are re-read
 // where they are used: a persistent loop otherwise keeps all ~50 scalar registers of pointers and sizes alive across
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
     kargs_t p = fresh(ka);
     const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(p->a.ws + kWsOrder), __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
-    if (w != p->a.seq) return;
+    if (w != p->a.seq && !(p->a.flags & kFlagSorted)) return;
   }
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
@@ -831,11 +840,18 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
     const size_t q_end = p->a.q_end;
     const size_t q = p->a.q_begin + (size_t)pd.tile * kPTile + threadIdx.x;
     uint64_t *off = p->a.offsets;
+    const uint32_t *perm = p->a.perm;
     if (pd.slab) {
       const uint32_t loff = pd.st >> 15, cnt = pd.st & 127u;
       if (q < q_end) {
-        stream_store(off + q, wpos0 + loff);
-        if (q == q_end - 1) off[q_end] = wpos0 + loff + cnt;
+        if (perm) {  // (bivx_self_overlaps_dev: count and list position go where the query's id says)
+          const uint32_t dst = perm[q];
+          p->a.dst_counts[dst] = cnt;
+          if (cap != 0) p->a.src_by_id[dst] = wpos0 + loff;
+        } else {
+          stream_store(off + q, wpos0 + loff);
+          if (q == q_end - 1) off[q_end] = wpos0 + loff + cnt;
+        }
       }
       if (ids) {
         wave_sync_lds();  // the slab is in place
@@ -877,8 +893,14 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
       }
     } else {
       if (q < q_end) {
-        off[q] = wpos0 + pd.x;
-        if (q == q_end - 1) off[q_end] = wpos0 + pd.x + pd.st;
+        if (perm) {
+          const uint32_t dst = perm[q];
+          p->a.dst_counts[dst] = pd.st;
+          if (cap != 0) p->a.src_by_id[dst] = wpos0 + pd.x;
+        } else {
+          off[q] = wpos0 + pd.x;
+          if (q == q_end - 1) off[q_end] = wpos0 + pd.x + pd.st;
+        }
       }
       if (cap != 0 && lane == 0) {
         uint64_t *ws = p->a.ws;
@@ -1048,7 +1070,7 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
     const size_t q = a.q_begin + (size_t)(e >> 4) * kPTile + (size_t)(e & 15u) * kWave + lane;
     const bool valid = q < a.q_end;
     const Query qy = load_query<false>(v, cs, a.qchrom, a.qlow, a.qhigh, q, valid);
-    const uint64_t pos = valid ? a.offsets[q] : 0;
+    const uint64_t pos = !valid ? 0 : a.perm ? a.src_by_id[a.perm[q]] : a.offsets[q];
     (void)enumerate_hits<Mode::Fill, false>(v, segs, qy, a.hits, pos, a.cap, nullptr);
     if (S) {
       // ascending ids were asked for: the slice's 64 lists are ordered here, where they were just written (asking for
@@ -1136,7 +1158,8 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
     }
   }
-  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, sort_seq, d_counts, d_total};
+  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, sort_seq, d_counts, d_total,
+             nullptr, nullptr, nullptr};
   if (sort_seq)
     hipLaunchKernelGGL(k_query_pipe<true>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   else
@@ -1164,11 +1187,125 @@ int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const 
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
     }
   }
-  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, seq, nullptr, nullptr};
+  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, seq, nullptr, nullptr,
+             nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_probe_order, dim3(1), dim3(256), 0, s, d_qchrom, d_qlow, q0, q1, ws, seq);
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   a.seq = 0;  // (k_fill_slices: index order)
   hipLaunchKernelGGL(k_fill_slices<false>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+// The index overlapped with itself (bivx_self_overlaps_dev): the queries are the index's own intervals in SLOT order —
+// position-sorted by construction, which is what k_query_pipe_dense is for — and the result is wanted in id order:
+// perm = the slots' ids. The kernel writes the lists back to back in slot order into d_tmp_hits and leaves, per id, the
+// list's length and where it begins; offsets are a scan of the lengths; k_permute_lists gathers the lists into place.
+// (Writing every list straight to its place from the slot-order pass was tried first: 50 M lists of ~68 bytes at random
+// places of a 3.4 GB buffer are partial-line writes the memory side has to read-modify-write: 6.1 ms for that pass at
+// config 5. Random READS of the same lists run at the gather rate, and the writes are a stream.)
+bool self_overlaps_eligible(const IndexView &v, size_t n) {
+  const char *env = std::getenv("BIVX_PIPE");
+  const int mode = env ? std::atoi(env) : 1;
+  if (!mode || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
+  if (v.nslots > (1u << 28) || v.max_cell > kMaxCellForPipe) return false;
+  return n >= (size_t)64 * kPTile || mode == 2;
+}
+
+// result list i = d_tmp[src[i] .. src[i] + (offsets[i + 1] - offsets[i])), written to d_hits[offsets[i] ..). A wavefront
+// takes 64 consecutive lists — one contiguous piece of the output — and every lane one output element at a time: the
+// element's list is found by bisection of the 64 list ends in LDS, its source is a gather, the stores are a stream.
+__global__ __launch_bounds__(kQThreads) void k_permute_lists(const uint64_t *__restrict__ offsets,
+                                                             const uint64_t *__restrict__ src, const uint32_t *__restrict__ tmp,
+                                                             uint32_t *__restrict__ hits, size_t n, uint64_t cap) {
+  __shared__ uint32_t s_end[kQWaves][kWave];
+  __shared__ uint64_t s_src[kQWaves][kWave];
+  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * kQThreads + threadIdx.x;
+  const uint64_t o0 = offsets[i < n ? i : n], o1 = offsets[i < n ? i + 1 : n];
+  const uint64_t wb = __shfl((unsigned long long)o0, 0, kWave);  // the wavefront's piece of the output: [wb, we)
+  const uint64_t we = __shfl((unsigned long long)o1, kWave - 1, kWave);
+  if (we - wb > 0xFFFFFFFFull) {  // (more than 2^32 ids in 64 lists: every lane copies its own)
+    if (i < n)
+      for (uint64_t k = 0; k < o1 - o0; ++k)
+        if (o0 + k < cap) hits[o0 + k] = tmp[src[i] + k];
+    return;
+  }
+  s_end[wave][lane] = (uint32_t)(o1 - wb);
+  s_src[wave][lane] = i < n ? src[i] - (o0 - wb) : 0ull;  // source of the list's first element, minus its place in the piece
+  wave_sync_lds();
+  const uint32_t total = (uint32_t)(we - wb);
+  // every lane one output element of four consecutive rows of 64 per trip: four bisections, then four gathers in flight,
+  // then four row stores (each row a 256-byte stream). (One row per trip: 3.3 ms at config 5; four consecutive
+  // elements per lane moved as 16 bytes — unaligned gathers and stores — 4.9.)
+  constexpr uint32_t kRowsPerTrip = 4;
+  for (uint32_t e0 = lane; e0 < total; e0 += kWave * kRowsPerTrip) {
+    uint32_t owner[kRowsPerTrip];
+#pragma unroll
+    for (uint32_t r = 0; r < kRowsPerTrip; ++r) {
+      const uint32_t e = e0 + r * kWave;
+      uint32_t lo = 0, hi = kWave - 1;  // first list whose end is beyond e
+#pragma unroll
+      for (int step = 0; step < 6; ++step) {  // (64 lists: six halvings, branch-free)
+        const uint32_t m = (lo + hi) >> 1;
+        const bool right = s_end[wave][m] <= e;
+        lo = right ? m + 1 : lo;
+        hi = right ? hi : m;
+      }
+      owner[r] = lo < kWave ? lo : kWave - 1;
+    }
+    uint32_t x[kRowsPerTrip];
+    bool ok[kRowsPerTrip];
+#pragma unroll
+    for (uint32_t r = 0; r < kRowsPerTrip; ++r) {
+      const uint32_t e = e0 + r * kWave;
+      const uint64_t sp = s_src[wave][owner[r]] + e;
+      ok[r] = e < total && wb + e < cap && sp < cap;
+      x[r] = ok[r] ? stream_load(tmp + sp) : 0u;
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kRowsPerTrip; ++r)
+      if (ok[r]) stream_store(hits + wb + e0 + r * kWave, x[r]);
+  }
+}
+
+int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                         const uint32_t *d_perm, size_t n, uint32_t *d_counts, uint64_t *d_src_by_id,
+                         uint64_t *d_offsets_scratch, uint32_t *d_tmp_hits, uint64_t cap, uint64_t *ws, bool self_clean,
+                         hipStream_t s) {
+  const int flags = (self_clean ? kFlagSelfClean : 0) | kFlagFinal | kFlagSorted;
+  unsigned wgs = 512;
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      wgs = 2u * (unsigned)cus;
+    if (const char *e = std::getenv("BIVX_PIPE_WGS")) {
+      const long w = std::atol(e);
+      if (w >= 1 && w <= 65536) wgs = (unsigned)w;
+    }
+  }
+  if (n > pipe_queries_per_launch()) {  // (launches would have to chain their output positions: not needed below 62 M)
+    set_error("bivx_self_overlaps_dev: more than %zu intervals", pipe_queries_per_launch());
+    return BIVX_E_RANGE;
+  }
+  const unsigned tiles = (unsigned)((n + kPTile - 1) / kPTile);
+  PipeArgs a{d_qchrom, d_qlow, d_qhigh, 0, n, d_offsets_scratch, d_tmp_hits, cap, ws, tiles, flags, 1u,
+             nullptr, nullptr, d_perm, d_src_by_id, d_counts};
+  hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
+  if (cap != 0) {
+    a.seq = 0;  // (k_fill_slices: index order)
+    hipLaunchKernelGGL(k_fill_slices<false>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
+  }
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
+                         uint64_t cap, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_permute_lists, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s, d_offsets,
+                     d_src, d_tmp, d_hits, n, cap);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

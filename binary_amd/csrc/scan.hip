@@ -1,0 +1,135 @@
+// scan.hip — device-wide exclusive prefix sum (u32 counts -> u64 offsets), hand-written for gfx950: per-query hit counts
+// to CSR offsets where a call produces the counts in another order than the offsets (bivx_self_overlaps_dev).
+//
+// Three launches: per-tile reduce -> single-workgroup scan of the tile sums -> per-tile scan + base.
+// Pure HBM streaming: reads the input twice (8 B/elem for u32) and writes the output once.
+#include "common.h"
+
+namespace bivx {
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;  // 2048 elements per workgroup
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+  const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    T o = __shfl_up(v, d, kWave);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread across the workgroup; returns the exclusive prefix and the
+// workgroup total through `total`. lds must hold (blockDim.x / 64) entries.
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *lds, T &total) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nwave = blockDim.x >> 6;
+  T incl = wave_inclusive_scan(v);
+  if (lane == kWave - 1) lds[wave] = incl;
+  __syncthreads();
+  T wave_base = 0, tot = 0;
+  for (int w = 0; w < nwave; ++w) {
+    T s = lds[w];
+    if (w < wave) wave_base += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return wave_base + incl - v;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(kScanThreads) void k_tile_reduce(const uint32_t *__restrict__ in, size_t n,
+                                                              OutT *__restrict__ sums) {
+  __shared__ OutT lds[kScanThreads / kWave];
+  const size_t base = (size_t)blockIdx.x * kScanTile;
+  OutT acc = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    size_t i = base + (size_t)k * kScanThreads + threadIdx.x;  // coalesced, order is irrelevant for a sum
+    if (i < n) acc += in[i];
+  }
+  OutT total;
+  (void)block_exclusive_scan<OutT>(acc, lds, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// one workgroup walks all tile sums (nb is small: n / 2048), leaves exclusive prefixes in place and the
+// grand total in sums[nb].
+template <typename OutT>
+__global__ __launch_bounds__(1024) void k_sums_scan(OutT *__restrict__ sums, size_t nb) {
+  __shared__ OutT lds[1024 / kWave];
+  OutT carry = 0;
+  for (size_t c = 0; c < nb; c += 1024) {
+    size_t i = c + threadIdx.x;
+    OutT v = i < nb ? sums[i] : 0;
+    OutT total;
+    OutT ex = block_exclusive_scan<OutT>(v, lds, total);
+    if (i < nb) sums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) sums[nb] = carry;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(kScanThreads) void k_tile_scan(const uint32_t *__restrict__ in, size_t n,
+                                                            const OutT *__restrict__ sums, size_t nb,
+                                                            OutT *__restrict__ out) {
+  __shared__ OutT lds[kScanThreads / kWave];
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;  // blocked
+  uint32_t v[kScanItems];
+  if (base + kScanItems <= n) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(in + base);
+    const uint4 b = *reinterpret_cast<const uint4 *>(in + base + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
+  }
+  OutT tsum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) tsum += v[k];
+  OutT total;
+  OutT run = block_exclusive_scan<OutT>(tsum, lds, total) + sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];
+}
+
+template <typename OutT>
+int exclusive_scan_impl(const uint32_t *d_in, OutT *d_out, size_t n, void *d_scratch, hipStream_t s) {
+  OutT *sums = static_cast<OutT *>(d_scratch);
+  if (n == 0) {
+    BIVX_HIP(hipMemsetAsync(d_out, 0, sizeof(OutT), s));
+    return 0;
+  }
+  const size_t nb = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_tile_reduce<OutT>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, d_in, n, sums);
+  hipLaunchKernelGGL(k_sums_scan<OutT>, dim3(1), dim3(1024), 0, s, sums, nb);
+  hipLaunchKernelGGL(k_tile_scan<OutT>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, d_in, n, sums, nb, d_out);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+size_t scan_scratch_bytes(size_t n) {
+  const size_t nb = (n + kScanTile - 1) / kScanTile;
+  return (nb + 2) * sizeof(uint64_t);
+}
+
+int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s) {
+  return exclusive_scan_impl<uint64_t>(d_in, d_out, n, d_scratch, s);
+}
+
+}  // namespace bivx

@@ -295,6 +295,19 @@ class IntervalIndex:
                                             0 if workspace is None else workspace.numel(), s))
         return begin, count, hits, total
 
+    def self_overlaps_device(self, offsets, hits, sort_by_id: bool = False):
+        """The index overlapped with itself (bivx_self_overlaps_dev): query i is appended interval i. offsets int64[n+1]
+        and hits are caller-owned device tensors; offsets[-1] is the true total even if it exceeds hits.numel().
+        Same CSR as query_device(low, high, qchrom=chrom) of the appended columns; asynchronous."""
+        self._ensure_built()
+        n = self.size()
+        _check_dev_tensor(offsets, "offsets", n + 1, 8)
+        _check_dev_tensor(hits, "hits")
+        s = C.c_void_p(torch.cuda.current_stream(offsets.device).cuda_stream)
+        capi.check(self._L.bivx_self_overlaps_dev(self._h, 1 if sort_by_id else 0, _tptr(offsets), _tptr(hits),
+                                                  hits.numel(), s))
+        return offsets, hits
+
     def find_overlaps_device(self, qlow, qhigh, qchrom=None, sort_by_id: bool = False):
         """(offsets int64[q+1], hits int32[H]) as device tensors. One host sync to size the hit buffer."""
         offsets = self.count_overlaps_device(qlow, qhigh, qchrom)

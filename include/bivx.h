@@ -51,7 +51,7 @@ typedef enum bivx_status {
 #define BIVX_NO_HIT 0xFFFFFFFFu
 
 /* ABI version of this header: major << 16 | minor. */
-#define BIVX_ABI_VERSION 0x00020000u
+#define BIVX_ABI_VERSION 0x00020001u
 uint32_t bivx_abi_version(void);
 const char *bivx_last_error(void);
 
@@ -259,6 +259,20 @@ int bivx_query_dev_u(const bivx_index *idx, const uint32_t *d_qchrom, const uint
                      const uint32_t *d_qhigh, size_t q, const bivx_filter *filter, uint64_t *d_begin,
                      uint32_t *d_count, uint32_t *d_hit_ids, uint64_t hit_capacity, uint64_t *d_total,
                      void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The index overlapped with itself: query i is appended interval i, i.e. the CSR bivx_query_dev_s gives for the
+ * appended columns as the batch (d_offsets[n + 1], n = bivx_size; query i's own id is among its hits) — the
+ * whole-genome self-overlap of one SV call set (BASELINE config 5; reference pattern: build the tree from a file's
+ * records and run find_overlaps for each of the same records, mapper.hpp:199-218 with sv == nl). The library answers
+ * in the index's OWN order, where neighbouring queries read neighbouring records (every line of the index is fetched
+ * once per wavefront instead of once per query), and then gathers the lists into id order; no query arrays are read.
+ * Same offsets and the same ids as the general call, list by list in the same order. It keeps a per-stream scratch of
+ * 12 n + 4 hit_capacity bytes. d_offsets[n] is the true total even when it exceeds hit_capacity — the contents of
+ * d_hit_ids are then unspecified and the call is repeated with a buffer of at least the total (hit_capacity 0 gives
+ * the offsets only). Indexes the fast path does not cover (several length classes per chromosome, positional
+ * hotspots, fewer than 61 440 intervals) take the general call, with its semantics. */
+int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_offsets, uint32_t *d_hit_ids,
+                           uint64_t hit_capacity, void *stream);
 
 /* Testing hook (tests/test_gpu_errors.py): overwrites the ticket word of the prefix workspace the index keeps for
  * `stream`, as a launch that died half-way would leave it, so that the next single-pass call on that stream finds

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "binary_amd", "csrc")
-DEFAULT = ("query_fused.hip", "query_pipe.hip", "query.hip", "build.hip")
+DEFAULT = ("query_fused.hip", "query_pipe.hip", "query.hip", "build.hip", "scan.hip")
 
 
 def demangle(names):
