@@ -165,7 +165,11 @@ __device__ __forceinline__ uint32_t eval16(const char *rb, uint32_t p0, uint32_t
   uint4 r[8];
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j)
+#ifdef BIVX_EXP_MAXLOADS  // experiment (wrong results): at most this many record loads per lane
+    if (p0 + j <= plast && j < BIVX_EXP_MAXLOADS) r[j] = *reinterpret_cast<const uint4 *>(rb + ((p0 + j) << 4));
+#else
     if (p0 + j <= plast) r[j] = *reinterpret_cast<const uint4 *>(rb + ((p0 + j) << 4));
+#endif
   uint32_t m = 0;
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j) {
@@ -205,6 +209,109 @@ __device__ __forceinline__ uint32_t lanes_mask32(const uint2 *rec, const Win &w,
   if (__any(b > al + 16u)) {
     if (b > al + 16u) m |= eval16<KEEP>(rb, p0 + 8u, plast, wm >> 16, w.base, qh, ql, keep, kpos) << 16;
   }
+  return m;
+}
+
+// The same windows fetched by GROUPS of eight lanes (the default; -DBIVX_NO_COOP keeps lanes_mask32). What bounds the
+// counting of scattered windows is the number of separate requests the vector memory pipeline has to make, not their
+// bytes: with up to eight predicated 16-byte loads per lane a slice is ~350 requests of 16 bytes, and the kernel's time
+// falls 0.323 -> 0.200 ms (config 3) when every lane makes at most ONE of them (wrong results, measured); one workgroup
+// per CU runs as fast as two. Here the eight lanes of a group (lanes 8g .. 8g+7) fetch ONE window together in every
+// round — lane p its p-th pair of records, 128 consecutive bytes per group, 8 windows per load instruction — and the
+// rounds k = 0 .. 7 go through the group's own queries (round k: the window of lane 8g + k): ~12 requests per
+// instruction instead of 64. The query's parameters travel to the group by ds_swizzle (the LDS crossbar, no memory):
+// three words — first pair | pairs << 27 | q.low bit 16 << 31; the window's base coordinate; q.low | q.high << 16 relative
+// to it (clamped to 17 / 16 bits, which the comparisons cannot tell from the full values). Both records of a lane are
+// evaluated as in eval16; the two ballots carry, in byte g, the hits of group g's even / odd slots: the round's owner
+// keeps its two bytes, and every lane of the group ranks its own hits among them and puts their ids into the OWNER's
+// keep slots (the first KEEP hits). A group does not know where inside its first and last pair the window begins and
+// ends (a is odd, b - al is odd): it reports RAW hits, and the owner — which does — trims the mask and skips what a
+// false first hit put into its keep slot 0. Returns the hit mask (bit j <-> slot al + j); `kinfo` = keep slots to skip
+// | usable kept ids << 1.
+__device__ __forceinline__ uint32_t spread8(uint32_t x) {  // bit i -> bit 2i
+  x = (x | x << 4) & 0x0F0Fu;
+  x = (x | x << 2) & 0x3333u;
+  return (x | x << 1) & 0x5555u;
+}
+
+template <uint32_t KEEP>
+__device__ __forceinline__ uint32_t coop_mask32(const uint2 *rec, uint32_t *keep_of_wave, const Win &w, bool nonempty,
+                                                uint32_t lo, uint32_t hi, uint32_t lane, uint32_t &kinfo) {
+  const uint32_t al = w.a & ~1u;
+  const uint32_t n = nonempty ? w.b - al : 0u;  // slots from al to the window's end, < 32
+  const uint32_t npairs = (n + 1u) >> 1;
+  uint32_t qh = hi - w.base, ql = lo > w.base ? lo - w.base : 0u;
+  qh = qh > 0xFFFFu ? 0xFFFFu : qh;      // (a record's low is 16 bits, low + length 17)
+  ql = ql > 0x1FFFFu ? 0x1FFFFu : ql;
+  const uint32_t w2 = (ql & 0xFFFFu) | qh << 16;
+  const char *rb = reinterpret_cast<const char *>(rec);
+  const uint32_t p = lane & 7u, gsh = (lane >> 3) * 8u, below = (1u << p) - 1u;
+  uint32_t *const kbase = keep_of_wave + (lane & 0x38u);  // + rank * 64 + k: slot `rank` of the round's owner
+  uint32_t rawA = 0, rawB = 0;  // the owner's bytes of its own round
+
+#define BIVX_COOP_ROUND(k, W0, KEEPIDS, OUTA, OUTB)                                                                   \
+  {                                                                                                                   \
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(W0), 0x18 | ((k) << 5));                          \
+    const uint32_t s1 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w.base, 0x18 | ((k) << 5));                       \
+    const uint32_t s2 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w2, 0x18 | ((k) << 5));                           \
+    const bool act = p < ((s0 >> 27) & 15u);                                                                          \
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);                                                                             \
+    if (act) r = *reinterpret_cast<const uint4 *>(rb + (((s0 & 0x7FFFFFFu) + p) << 4));                              \
+    const uint32_t sql = (s2 & 0xFFFFu) | (s0 >> 31) << 16, sqh = s2 >> 16;                                           \
+    const uint32_t la = (r.x - s1) & 0xFFFFu, lb = (r.z - s1) & 0xFFFFu;                                              \
+    const uint64_t live = __ballot(act);                                                                              \
+    const uint64_t hA = __builtin_amdgcn_uicmp(la, sqh, 37) & __builtin_amdgcn_uicmp(la + (r.x >> 16), sql, 35) & live; \
+    const uint64_t hB = __builtin_amdgcn_uicmp(lb, sqh, 37) & __builtin_amdgcn_uicmp(lb + (r.z >> 16), sql, 35) & live; \
+    const uint32_t bA = (uint32_t)(hA >> gsh) & 0xFFu, bB = (uint32_t)(hB >> gsh) & 0xFFu;                            \
+    if (p == (k)) {                                                                                                   \
+      OUTA = bA;                                                                                                      \
+      OUTB = bB;                                                                                                      \
+    }                                                                                                                 \
+    if (KEEPIDS) {                                                                                                    \
+      const uint32_t ra = (uint32_t)__popc(bA & below) + (uint32_t)__popc(bB & below), rbk = ra + ((bA >> p) & 1u);   \
+      if (((bA >> p) & 1u) != 0u && ra < KEEP) kbase[ra * kWave + (k)] = r.y;                                          \
+      if (((bB >> p) & 1u) != 0u && rbk < KEEP) kbase[rbk * kWave + (k)] = r.w;                                        \
+    }                                                                                                                 \
+  }
+
+  {
+    const uint32_t w0 = (al >> 1) | (npairs < 8u ? npairs : 8u) << 27 | (ql >> 16) << 31;
+    BIVX_COOP_ROUND(0, w0, true, rawA, rawB)
+    BIVX_COOP_ROUND(1, w0, true, rawA, rawB)
+    BIVX_COOP_ROUND(2, w0, true, rawA, rawB)
+    BIVX_COOP_ROUND(3, w0, true, rawA, rawB)
+    BIVX_COOP_ROUND(4, w0, true, rawA, rawB)
+    BIVX_COOP_ROUND(5, w0, true, rawA, rawB)
+    BIVX_COOP_ROUND(6, w0, true, rawA, rawB)
+    BIVX_COOP_ROUND(7, w0, true, rawA, rawB)
+  }
+  const uint32_t raw = spread8(rawA) | spread8(rawB) << 1;
+  const uint32_t wm = ((1u << n) - 1u) & ~(w.a - al);  // the window's own bits: [a - al, n); a - al is 0 or 1
+  uint32_t m = raw & wm & 0xFFFFu;
+  {
+    // kept ids: raw hits 0 .. min(raw hits, KEEP) - 1; the true ones among them: not a false first (slot al, a odd), not
+    // a false last (slot al + n, n odd)
+    const uint32_t rawcnt = (uint32_t)__popc(raw);
+    const uint32_t ff = raw & (w.a - al) & 1u;
+    const uint32_t fl = n < 16u ? (raw >> n) & 1u : 0u;
+    const uint32_t upto = rawcnt - fl < KEEP ? rawcnt - fl : KEEP;
+    kinfo = ff | (upto - ff) << 1;
+  }
+  if (__any(n > 16u)) {  // windows of 17 .. 31 slots (rare): their second sixteen the same way, ids are re-read later
+    uint32_t rawC = 0, rawD = 0;
+    const uint32_t np2 = npairs > 8u ? npairs - 8u : 0u;
+    const uint32_t w0 = ((al >> 1) + 8u) | np2 << 27 | (ql >> 16) << 31;
+    BIVX_COOP_ROUND(0, w0, false, rawC, rawD)
+    BIVX_COOP_ROUND(1, w0, false, rawC, rawD)
+    BIVX_COOP_ROUND(2, w0, false, rawC, rawD)
+    BIVX_COOP_ROUND(3, w0, false, rawC, rawD)
+    BIVX_COOP_ROUND(4, w0, false, rawC, rawD)
+    BIVX_COOP_ROUND(5, w0, false, rawC, rawD)
+    BIVX_COOP_ROUND(6, w0, false, rawC, rawD)
+    BIVX_COOP_ROUND(7, w0, false, rawC, rawD)
+    m |= ((spread8(rawC) | spread8(rawD) << 1) << 16) & wm;
+  }
+#undef BIVX_COOP_ROUND
   return m;
 }
 
@@ -516,6 +623,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     int path = 0;                  // how the slice was counted (wavefront-uniform), see below
     uint32_t qw_a = 0;             // paths 1 and 2: the window's first slot
     uint32_t m32 = 0, lbase = 0;   // paths 1 and 2: the hit mask (bit j <-> slot (a & ~1) + j); path 1: the slab's first slot
+    uint32_t kinfo = 0;            // path 2: keep slots to skip | usable kept ids << 1 (coop_mask32)
     uint32_t cnt = 0, loff = 0, wtotal = 0;
     bool staged = false, no_ids = false;
     uint64_t lpos64 = 0;
@@ -547,7 +655,13 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         m32 = slab_mask32(slab, lbase, w, qlo, qhi, nonempty);
         cnt = (uint32_t)__popc(m32);
       } else if (path == 2) {
+#ifdef BIVX_NO_COOP
         m32 = lanes_mask32<kPKeep>(fresh(ka)->v.rec, wn, nonempty, qlo, qhi, kept_slots());
+        kinfo = 0xFFFFFFFFu;
+#else
+        m32 = coop_mask32<kPKeep>(fresh(ka)->v.rec, reinterpret_cast<uint32_t *>(slab_of_wave()), wn, nonempty, qlo, qhi,
+                                  tid() & (kWave - 1), kinfo);
+#endif
         cnt = (uint32_t)__popc(m32);
       } else {
         kargs_t p = fresh(ka);
@@ -638,8 +752,13 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       }
     } else if (!no_ids && path == 2) {  // the first kPKeep ids are in the lane's keep slots; a longer list re-reads the rest
       uint32_t *dst = stage + loff;
+#ifdef BIVX_NO_COOP
       const uint32_t *kslots = kept_slots();
       const uint32_t nk = cnt < kPKeep ? cnt : kPKeep - 1u;  // (the last slot is only good while it was not the limit)
+#else
+      const uint32_t *kslots = kept_slots() + (kinfo & 1u) * kWave;  // (a false first hit sits in slot 0)
+      const uint32_t nk = cnt < (kinfo >> 1) ? cnt : kinfo >> 1;
+#endif
       for (uint32_t k = 0; k < nk; ++k) {
         dst[k] = kslots[k * kWave];
         m32 &= m32 - 1u;
