@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kStatsThreads) void k_bin_stats(const uint32_t *__r
                                                              const uint32_t *__restrict__ low,
                                                              const uint32_t *__restrict__ high, size_t n,
                                                              uint32_t nent, BinStats *__restrict__ stats) {
-  __shared__ BinStats lds[USE_LDS ? kStatsLdsEntries : 1];
+  extern __shared__ BinStats lds[];  // nent entries (USE_LDS): a small table leaves room for more workgroups per CU
   if (USE_LDS) {
     for (uint32_t e = threadIdx.x; e < nent; e += kStatsThreads) lds[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u, 0u};
     __syncthreads();
@@ -441,6 +441,8 @@ struct Gap {
   uint32_t first, count, value, pad;
 };
 
+constexpr uint32_t kFinSlots = 4;  // slots per thread, kThreads apart: their loads are all in flight together
+
 template <bool DENSE>
 __global__ __launch_bounds__(kThreads) void k_finalize(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ ids,
@@ -455,79 +457,113 @@ __global__ __launch_bounds__(kThreads) void k_finalize(const uint32_t *__restric
   const uint32_t per = (nchunks + 7u) / 8u;
   const uint32_t chunk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
   if ((blockIdx.x >> 3) >= per || chunk >= nchunks) return;  // (workgroup-uniform)
-  const size_t i = (size_t)chunk * kThreads + threadIdx.x;
+  const size_t i0 = (size_t)chunk * (kThreads * kFinSlots) + threadIdx.x;
   if (chunk == 0 && threadIdx.x < 2) {  // the two spare slots behind the arrays (query lanes read pairs of slots)
     se[n + threadIdx.x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     rec[n + threadIdx.x] = make_uint2(0u, 0u);
   }
-  const bool valid = i < n;
   const uint32_t lane = threadIdx.x & (kWave - 1);
-  // what this slot writes into the directory: entries [e0, e0 + cnt) = i, and behind a segment's last slot [t0, t0 + tcnt) = end
-  uint32_t e0 = 0, cnt = 0, t0 = 0, tcnt = 0, tval = 0;
-  if (valid) {
-    uint32_t lo = 0, hi = nseg;  // last segment with begin <= i
+  // the segment of the chunk's first slot: the last one with begin <= that slot (the others follow by stepping)
+  uint32_t s0 = 0;
+  {
+    const size_t first = (size_t)chunk * (kThreads * kFinSlots);
+    uint32_t lo = 0, hi = nseg;
     while (hi - lo > 1) {
       const uint32_t m = (lo + hi) >> 1;
-      if ((size_t)seg[m].begin <= i) lo = m; else hi = m;
+      if ((size_t)seg[m].begin <= first) lo = m; else hi = m;
     }
-    const SegDesc d = seg[lo];
-    // (the streams are touched once: non-temporal, so that they leave the L2 to the gathered column)
-    const uint32_t id = __builtin_nontemporal_load(ids + i);
-    uint2 k = make_uint2(0u, 0u);
-    uint32_t l;
-    if (DENSE) {
-      k = segkey[lo];
-      l = k.y + (__builtin_nontemporal_load(keys + i) - k.x);
-    } else {
-      l = low[id];
-    }
-    const uint32_t h = high[id];
-    unsigned long long *se64 = reinterpret_cast<unsigned long long *>(se), *rec64 = reinterpret_cast<unsigned long long *>(rec);
-    const uint32_t r = (d.shift & kSegPacked) ? ((l & 0xFFFFu) | ((h - l) << 16)) : 0u;
-    __builtin_nontemporal_store((unsigned long long)l | (unsigned long long)h << 32, se64 + i);
-    __builtin_nontemporal_store((unsigned long long)r | (unsigned long long)id << 32, rec64 + i);
-    // directory
-    const uint32_t sh = d.shift & 31u;
-    const uint32_t c = (l - d.base) >> sh;
-    uint32_t first = 0;
-    if (i > d.begin) {
-      const uint32_t lp = DENSE ? k.y + (keys[i - 1] - k.x) : low[ids[i - 1]];
-      first = ((lp - d.base) >> sh) + 1u;
-    }
-    e0 = d.table_off + first;
-    cnt = c + 1u - first;  // (0 when the slot shares its predecessor's cell)
-    if (i + 1 == d.end) {
-      t0 = d.table_off + c + 1u;
-      tcnt = d.ncell - c;
-      tval = d.end;
-    }
+    s0 = lo;
   }
-  const uint32_t val = (uint32_t)i;
-  if (cnt <= kInlineFill)
-    for (uint32_t c = 0; c < cnt; ++c) table[e0 + c] = val;
-  if (tcnt <= kInlineFill)
-    for (uint32_t c = 0; c < tcnt; ++c) table[t0 + c] = tval;
-  // longer stretches: the wavefront writes them, lane by lane (every lane of the wavefront is here)
-  auto cooperative = [&](bool pending, uint32_t b0, uint32_t bc, uint32_t bv) {
-    uint64_t pm = __ballot(pending);
-    while (pm) {
-      const int src = __ffsll((long long)pm) - 1;
-      pm &= pm - 1;
-      const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, src);
-      const uint32_t gc = (uint32_t)__builtin_amdgcn_readlane((int)bc, src);
-      const uint32_t gv = (uint32_t)__builtin_amdgcn_readlane((int)bv, src);
-      if (gc > kCoopMax) {
-        if (lane == 0) {
-          const uint32_t g = atomicAdd(ngaps, 1u);
-          if (g < gap_cap) gaps[g] = Gap{g0, gc, gv, 0u};  // (the capacity covers every stretch there can be)
-        }
+  // (the streams are touched once: non-temporal, so that they leave the L2 to the gathered column)
+  uint32_t id[kFinSlots], key[kFinSlots], prev[kFinSlots], h[kFinSlots];
+#pragma unroll
+  for (uint32_t j = 0; j < kFinSlots; ++j) {
+    const size_t i = i0 + (size_t)j * kThreads;
+    id[j] = key[j] = prev[j] = 0;
+    if (i < n) {
+      id[j] = __builtin_nontemporal_load(ids + i);
+      if (DENSE) {
+        key[j] = __builtin_nontemporal_load(keys + i);
+        prev[j] = i ? keys[i - 1] : 0u;
       } else {
-        for (uint32_t c = lane; c < gc; c += kWave) table[g0 + c] = gv;
+        prev[j] = i ? ids[i - 1] : 0u;
       }
     }
-  };
-  cooperative(cnt > kInlineFill, e0, cnt, val);
-  cooperative(tcnt > kInlineFill, t0, tcnt, tval);
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < kFinSlots; ++j) {
+    const size_t i = i0 + (size_t)j * kThreads;
+    h[j] = 0;
+    if (i < n) {
+      h[j] = high[id[j]];
+      if (!DENSE) {
+        key[j] = low[id[j]];
+        prev[j] = i ? low[prev[j]] : 0u;
+      }
+    }
+  }
+  unsigned long long *se64 = reinterpret_cast<unsigned long long *>(se), *rec64 = reinterpret_cast<unsigned long long *>(rec);
+#pragma unroll
+  for (uint32_t j = 0; j < kFinSlots; ++j) {
+    const size_t i = i0 + (size_t)j * kThreads;
+    const bool valid = i < n;
+    // what this slot writes into the directory: entries [e0, e0 + cnt) = i, and behind a segment's last slot [t0, t0 + tcnt) = end
+    uint32_t e0 = 0, cnt = 0, t0 = 0, tcnt = 0, tval = 0;
+    if (valid) {
+      uint32_t si = s0;
+      while (si + 1 < nseg && (size_t)seg[si + 1].begin <= i) ++si;
+      const SegDesc d = seg[si];
+      uint32_t l, lp;
+      if (DENSE) {
+        const uint2 k = segkey[si];
+        l = k.y + (key[j] - k.x);
+        lp = k.y + (prev[j] - k.x);
+      } else {
+        l = key[j];
+        lp = prev[j];
+      }
+      const uint32_t r = (d.shift & kSegPacked) ? ((l & 0xFFFFu) | ((h[j] - l) << 16)) : 0u;
+      __builtin_nontemporal_store((unsigned long long)l | (unsigned long long)h[j] << 32, se64 + i);
+      __builtin_nontemporal_store((unsigned long long)r | (unsigned long long)id[j] << 32, rec64 + i);
+      // directory
+      const uint32_t sh = d.shift & 31u;
+      const uint32_t c = (l - d.base) >> sh;
+      const uint32_t first = i > d.begin ? ((lp - d.base) >> sh) + 1u : 0u;
+      e0 = d.table_off + first;
+      cnt = c + 1u - first;  // (0 when the slot shares its predecessor's cell)
+      if (i + 1 == d.end) {
+        t0 = d.table_off + c + 1u;
+        tcnt = d.ncell - c;
+        tval = d.end;
+      }
+    }
+    const uint32_t val = (uint32_t)i;
+    if (cnt <= kInlineFill)
+      for (uint32_t c = 0; c < cnt; ++c) table[e0 + c] = val;
+    if (tcnt <= kInlineFill)
+      for (uint32_t c = 0; c < tcnt; ++c) table[t0 + c] = tval;
+    // longer stretches: the wavefront writes them, lane by lane (every lane of the wavefront is here)
+    auto cooperative = [&](bool pending, uint32_t b0, uint32_t bc, uint32_t bv) {
+      uint64_t pm = __ballot(pending);
+      while (pm) {
+        const int src = __ffsll((long long)pm) - 1;
+        pm &= pm - 1;
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, src);
+        const uint32_t gc = (uint32_t)__builtin_amdgcn_readlane((int)bc, src);
+        const uint32_t gv = (uint32_t)__builtin_amdgcn_readlane((int)bv, src);
+        if (gc > kCoopMax) {
+          if (lane == 0) {
+            const uint32_t g = atomicAdd(ngaps, 1u);
+            if (g < gap_cap) gaps[g] = Gap{g0, gc, gv, 0u};  // (the capacity covers every stretch there can be)
+          }
+        } else {
+          for (uint32_t c = lane; c < gc; c += kWave) table[g0 + c] = gv;
+        }
+      }
+    };
+    cooperative(cnt > kInlineFill, e0, cnt, val);
+    cooperative(tcnt > kInlineFill, t0, tcnt, tval);
+  }
 }
 
 // the listed stretches of directory entries, by the whole grid
@@ -603,10 +639,10 @@ int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t nt
   const uint32_t nent = nparts * kLenBins;
   hipLaunchKernelGGL(k_init_stats, dim3(grid_for(nent, kThreads)), dim3(kThreads), 0, s, d_stats, nent);
   if (n) {
-    const unsigned nb = grid_for(n, kStatsThreads * kStatsUnroll * 2, 1024);
+    const unsigned nb = grid_for(n, kStatsThreads * kStatsUnroll * 2, 2048);
     if (nent <= kStatsLdsEntries)
-      hipLaunchKernelGGL(k_bin_stats<true>, dim3(nb), dim3(kStatsThreads), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
-                         nent, d_stats);
+      hipLaunchKernelGGL(k_bin_stats<true>, dim3(nb), dim3(kStatsThreads), (size_t)nent * sizeof(BinStats), s, d_chrom,
+                         d_type, ntypes, d_low, d_high, n, nent, d_stats);
     else
       hipLaunchKernelGGL(k_bin_stats<false>, dim3(nb), dim3(kStatsThreads), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
                          nent, d_stats);
@@ -674,7 +710,7 @@ int launch_finalize(const uint32_t *d_keys, const uint32_t *d_ids, const uint32_
                     uint32_t *d_table, uint64_t nentries, void *d_gaps, uint32_t *d_ngaps, uint32_t *d_max_cell,
                     size_t n, hipStream_t s) {
   if (n == 0 || nseg == 0) return 0;
-  const uint32_t nchunks = grid_for(n, kThreads);
+  const uint32_t nchunks = grid_for(n, kThreads * kFinSlots);
   const unsigned grid = ((nchunks + 7u) / 8u) * 8u;
   const uint32_t cap = (uint32_t)finalize_gap_capacity(nentries, nseg);
   Gap *gaps = static_cast<Gap *>(d_gaps);
