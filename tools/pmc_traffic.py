@@ -13,9 +13,12 @@ from collections import defaultdict
 
 acc = defaultdict(list)
 KERNEL = "k_query_fused"
+STEP_KERNELS = None  # a step made of several kernels (bivx_self_overlaps_dev): their per-launch averages are added up
 if len(sys.argv) > 3:  # the bench line names the kernel that did the work
     try:
-        KERNEL = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])["roofline"]["dominant_kernel"]
+        rl = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])["roofline"]
+        KERNEL = rl["dominant_kernel"]
+        STEP_KERNELS = rl.get("step_kernels")
     except Exception:
         pass
 
@@ -36,6 +39,18 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         if not (skip_first and int(r["Dispatch_Id"]) == first):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
+if STEP_KERNELS:
+    per = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            for k in STEP_KERNELS:
+                if ("::" + k + "<") in r["Kernel_Name"] or ("::" + k + "(") in r["Kernel_Name"] or r["Kernel_Name"].rstrip().endswith(k):
+                    per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    avg = defaultdict(float)
+    for k in per:
+        for c, v in per[k].items():
+            avg[c] += sum(v) / len(v)
+    avg = dict(avg)
 rd = avg.get("TCC_EA0_RDREQ_sum", 0.0)
 rd32, rd64 = avg.get("TCC_EA0_RDREQ_32B_sum", 0.0), avg.get("TCC_EA0_RDREQ_64B_sum", 0.0)
 rd128 = avg.get("TCC_EA0_RDREQ_128B_sum", rd - rd32 - rd64)
@@ -44,7 +59,7 @@ wr = avg.get("TCC_EA0_WRREQ_sum", 0.0)
 wr64 = avg.get("TCC_EA0_WRREQ_64B_sum", 0.0)
 write_bytes_req = wr64 * 64 + (wr - wr64) * 32
 out = {
-    "kernel": KERNEL, "launches_sampled": len(acc.get("TCC_EA0_RDREQ_sum", [])),
+    "kernel": KERNEL if not STEP_KERNELS else " + ".join(STEP_KERNELS), "launches_sampled": len(acc.get("TCC_EA0_RDREQ_sum", [])),
     "counters_avg_per_launch": avg,
     "read_bytes_per_launch": read_bytes,
     "fetch_size_bytes_per_launch_uncorrected": avg.get("FETCH_SIZE", 0.0) * 1024,
