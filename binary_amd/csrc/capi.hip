@@ -253,6 +253,11 @@ int note_device_append(bivx_index *idx, hipStream_t s) {
     return 0;
   }
   idx->ev_pending.push_back(ev);
+  if (idx->ev_pending.size() > 256) {  // (thousands of appends without a build: wait once instead of piling events up)
+    BIVX_HIP(hipDeviceSynchronize());
+    for (hipEvent_t e : idx->ev_pending) idx->ev_free.push_back(e);
+    idx->ev_pending.clear();
+  }
   return 0;
 }
 

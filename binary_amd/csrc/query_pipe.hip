@@ -1328,6 +1328,7 @@ bool self_overlaps_eligible(const IndexView &v, size_t n) {
   const int mode = env ? std::atoi(env) : 1;
   if (!mode || v.flt_kind != BIVX_FILTER_NONE || v.max_segs > 1 || !fits_lds(v)) return false;
   if (v.nslots > (1u << 28) || v.max_cell > kMaxCellForPipe) return false;
+  if (n > pipe_queries_per_launch()) return false;  // (one launch: nothing chains output positions across launches)
   return n >= (size_t)64 * kPTile || mode == 2;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomized sessions: the pipelined kernels (BIVX_PIPE=2: every eligible batch) against k_query_fused (BIVX_PIPE=0) on
 random indexes, batches, orders, capacities, launch limits and workgroup counts — offsets and ids must be identical,
-and counts must equal the predicate's on a sample. usage (on the GPU box): fuzz_pipe.py [sessions=200] [first seed=0]"""
+and counts must equal the predicate's on a sample; and bivx_self_overlaps_dev against the general call on the same index. usage (on the GPU box): fuzz_pipe.py [sessions=200] [first seed=0]"""
 import os
 import sys
 
@@ -87,6 +87,26 @@ for seed in range(S0, S0 + N):
         for i in sel:
             m = (chrom == qc[i]) & (low <= qhi[i]) & (high >= qlo[i])
             ok = ok and int(m.sum()) == int(cnt[i])
+        # the index overlapped with itself: bivx_self_overlaps_dev (BIVX_PIPE=2: its fast path whenever the index allows
+        # it) against the general call with the appended columns as the batch (BIVX_PIPE=0)
+        self_ok = True
+        if n <= 400_000 or big:
+            d_lo, d_hi, d_c = to(low), to(high), to(chrom)
+            os.environ["BIVX_PIPE"] = "0"
+            soff0 = idx.count_overlaps_device(d_lo, d_hi, d_c)
+            SH = int(soff0[-1].item())
+            if SH < 400_000_000:
+                sh0 = torch.full((max(SH, 1),), -1, dtype=torch.int32, device=dev)
+                so0 = torch.empty(n + 1, dtype=torch.int64, device=dev)
+                idx.query_device(d_lo, d_hi, so0, sh0[:SH], qchrom=d_c, sort_by_id=by_id)
+                os.environ["BIVX_PIPE"] = "2"
+                sh1 = torch.full((max(SH, 1),), -1, dtype=torch.int32, device=dev)
+                so1 = torch.full((n + 1,), -1, dtype=torch.int64, device=dev)
+                idx.self_overlaps_device(so1, sh1[:SH], sort_by_id=by_id)
+                idx.stream_status()
+                self_ok = torch.equal(so0, so1) and torch.equal(sh0, sh1) and torch.equal(so0, soff0)
+            os.environ.pop("BIVX_PIPE", None)
+        ok = ok and self_ok
         st = idx.stats()
         ok = ok and st["prefix_timeouts"] == 0
     tag = "ok " if ok else "BAD"
