@@ -24,39 +24,40 @@ namespace sv2nl {
   namespace tree = binary::algorithm::tree;
   namespace vcf = binary::parser::vcf;
 
-  struct Sv2nlInfoField : public vcf::BaseInfoField {
-    std::string svtype{};
-    vcf::pos_t svend{};  // as written in the file (a 1-based coordinate, not shifted)
-
-    std::string chr2{};
-    bool strand1{true};  // true: '+'
-    bool strand2{true};
+  struct Sv2nlInfoField final : vcf::BaseInfoField {
+    // what sv2nl keeps of a record's INFO column
+    std::string svtype;
+    vcf::pos_t svend = 0;  // as written in the file (a 1-based coordinate, not shifted)
+    std::string chr2;      // TRA / BND records only
+    bool strand1 = true;   // INV records only; true: '+'
+    bool strand2 = true;
 
     void update(std::shared_ptr<vcf::details::DataImpl> const &data, std::string_view source) override {
-      const auto *h = data->header.get();
-      const auto *r = data->record.get();
-      svtype = vcf::get_info_field<char>("SVTYPE", h, r);
-      chr2.clear();
-      strand1 = strand2 = true;
+      const auto *hdr = data->header.get();
+      const auto *rec = data->record.get();
+      auto text = [&](const char *tag) { return vcf::get_info_field<char>(tag, hdr, rec); };
+      svtype = text("SVTYPE");
       const bool bnd = svtype == "BND";
-      if (bnd || svtype == "TRA") chr2 = vcf::get_info_field<char>("CHR2", h, r);
+      chr2 = bnd || svtype == "TRA" ? text("CHR2") : std::string();
+      strand1 = strand2 = true;
       if (svtype == "INV") {
-        try {
-          strand1 = vcf::get_info_field<char>("STRAND1", h, r) == "+";
-          strand2 = vcf::get_info_field<char>("STRAND2", h, r) == "+";
+        try {  // ONE block for both: without STRAND1 the second tag is not looked at
+          strand1 = text("STRAND1") == "+";
+          strand2 = text("STRAND2") == "+";
         } catch (...) {  // files without strands: both stay '+', as in the reference
         }
       }
-      svend = vcf::get_info_field<vcf::pos_t>(bnd ? "POS2" : source == "nls" ? "SVEND" : "END", h, r);
-    }
-
-    friend auto operator<<(std::ostream &os, Sv2nlInfoField const &i) -> std::ostream & {
-      return os << "svtype: " << i.svtype << " svend: " << i.svend;
-    }
-    friend auto operator==(Sv2nlInfoField const &a, Sv2nlInfoField const &b) -> bool {
-      return a.svtype == b.svtype && a.svend == b.svend;
+      const char *end_tag = bnd ? "POS2" : source == "nls" ? "SVEND" : "END";
+      svend = vcf::get_info_field<vcf::pos_t>(end_tag, hdr, rec);
     }
   };
+
+  inline auto operator<<(std::ostream &os, Sv2nlInfoField const &i) -> std::ostream & {
+    return os << "svtype: " << i.svtype << " svend: " << i.svend;
+  }
+  inline auto operator==(Sv2nlInfoField const &a, Sv2nlInfoField const &b) -> bool {
+    return a.svend == b.svend && a.svtype == b.svtype;
+  }
 
   using Sv2nlVcfRecord = vcf::BaseVcfRecord<Sv2nlInfoField>;
   using Sv2nlVcfRanges = vcf::VcfRanges<Sv2nlVcfRecord>;

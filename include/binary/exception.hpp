@@ -3,22 +3,18 @@
 // binary::VcfReaderError is what the reference's VcfParser throws (library/include/binary/exception.hpp:13-20) and what
 // code written against it catches; binary/parser/vcf.hpp here raises it in the same situations (unreadable file, a
 // line that is not a VCF record, an INFO tag that is undeclared, of another type, or absent from the record).
+// A std::runtime_error underneath (the reference derives from std::exception directly): what() is the message either
+// way, and a handler for std::exception or for VcfReaderError catches both forms.
 #ifndef BINARY_AMD_EXCEPTION_HPP_
 #define BINARY_AMD_EXCEPTION_HPP_
 
-#include <exception>
+#include <stdexcept>
 #include <string>
-#include <utility>
 
 namespace binary {
 
-  class VcfReaderError : public std::exception {
-  public:
-    explicit VcfReaderError(std::string text) : text_(std::move(text)) {}
-    [[nodiscard]] auto what() const noexcept -> const char * override { return text_.c_str(); }
-
-  private:
-    std::string text_;
+  struct VcfReaderError : std::runtime_error {
+    using std::runtime_error::runtime_error;
   };
 
 }  // namespace binary
