@@ -78,3 +78,26 @@ def test_find_overlaps_on_the_six_record_tree_vs_oracle(vcf_facade_binary, tmp_p
         assert sorted(exp) == brute
         nonempty += bool(exp)
     assert nonempty >= 10
+
+
+@pytest.mark.gpu
+def test_per_record_caller_written_against_the_dropin_types(tmp_path):
+    """tests/cpp/dropin_dup_mapper.cpp: the reference's DUP mapper pattern (a tree per chromosome from a filter | transform
+    view, one find_overlaps(record) per NL record, check_condition, the duplicate-key rule, the line format:
+    mapper.hpp:147-162,194-236, mapper.cpp:50-55) written against nothing but the drop-in headers. Its lines equal the
+    expected TSV of the authored pair fixture — the lines the oracle-derived golden file and the batched tool give."""
+    from binary_amd import _build
+    _build.build_lib()
+    exe = str(tmp_path / "dropin_dup_mapper")
+    libdir = os.path.join(ROOT, "binary_amd")
+    r = subprocess.run(["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "dropin_dup_mapper.cpp"), "-o", exe, "-L", libdir, "-lbivx", "-lz",
+                        "-pthread", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for dis, expected in (("1000000", "pair_expected.dup.tsv"), ("50000", "pair_expected_short_dis50000.dup.tsv")):
+        r = subprocess.run([exe, os.path.join(FIXTURES, "pair_sv.vcf"), os.path.join(FIXTURES, "pair_nl.vcf"), dis],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got = sorted(l for l in r.stdout.splitlines()[1:] if l)
+        exp = sorted(l for l in open(os.path.join(FIXTURES, expected)).read().splitlines()[1:] if l)
+        assert got == exp and len(exp) > 20, (dis, len(got), len(exp))
