@@ -24,11 +24,31 @@ __device__ __forceinline__ uint32_t len_bin(uint32_t low, uint32_t high, uint32_
 // broadcast, they do not serialise) and only a wavefront in which some lane would improve an entry reduces those lanes'
 // values (DPP) and lets one lane issue the atomics. Steps measured at 10 M intervals (a 120 MB read): five LDS atomics
 // per interval, one chunk of 64 per wavefront and trip: 169 us; everything reduced per distinct key in every wavefront:
-// 149; counts by a scalar loop over the wavefront's keys + the conditional extrema: 152, with four chunks in flight 103.
+// 149; counts by a scalar loop over the wavefront's keys + the conditional extrema: 152, with four chunks in flight 103;
+// one LDS atomic per interval: 72. Then the cost was per WORKGROUP, not per interval — every workgroup ends by adding its
+// table to the global one, ~360 device atomics on the same 360 addresses whatever the grid: 2 048 workgroups of 512
+// threads 77 us, 256 of 1 024 (one per CU, eight chunks in flight per wavefront) 46 us = 2.6 TB/s; 50 M intervals 178 us =
+// 3.4 TB/s. (The BIVX_STATS_* macros are tools/ab_build.sh's knobs.)
 
 constexpr uint32_t kStatsLdsEntries = 3300;  // (partition, bin) pairs privatised in LDS (100 partitions: 66 KB)
-constexpr int kStatsThreads = 512;
-constexpr int kStatsUnroll = 4;            // chunks of 64 intervals a wavefront has in flight
+#ifndef BIVX_STATS_PARTS
+#define BIVX_STATS_PARTS 64
+#endif
+constexpr uint32_t kStatsAutoParts = BIVX_STATS_PARTS;     // chromosome ids the one-pass form (no svtypes) has a table for
+#ifndef BIVX_STATS_THREADS
+#define BIVX_STATS_THREADS 1024
+#endif
+constexpr int kStatsThreads = BIVX_STATS_THREADS;
+#ifndef BIVX_STATS_UNROLL
+#define BIVX_STATS_UNROLL 8
+#endif
+#ifndef BIVX_STATS_TRIPS
+#define BIVX_STATS_TRIPS 1
+#endif
+#ifndef BIVX_STATS_CAP
+#define BIVX_STATS_CAP 256
+#endif
+constexpr int kStatsUnroll = BIVX_STATS_UNROLL;            // chunks of 64 intervals a wavefront has in flight
 
 // the partition ("virtual chromosome") of interval i: chrom * ntypes + svtype (include/bivx.h, bivx_append_typed)
 __device__ __forceinline__ uint32_t part_of(const uint32_t *__restrict__ chrom, const uint8_t *__restrict__ type,
@@ -41,12 +61,17 @@ __device__ __forceinline__ uint32_t peek(const uint32_t *p) {  // (a plain read 
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool USE_LDS>
+// AUTO (no svtypes; USE_LDS): the number of chromosomes is not known yet. The table has nent / kLenBins rows: the host reads
+// the largest chromosome id off the rows that came back non-empty, unless the kernel met an id beyond the table — then
+// scal[0] holds the largest such id and the host repeats the pass with a table of the right size. One pass over the columns
+// and one read-back instead of two of each.
+template <bool USE_LDS, bool AUTO = false>
 __global__ __launch_bounds__(kStatsThreads) void k_bin_stats(const uint32_t *__restrict__ chrom,
                                                              const uint8_t *__restrict__ type, uint32_t ntypes,
                                                              const uint32_t *__restrict__ low,
                                                              const uint32_t *__restrict__ high, size_t n,
-                                                             uint32_t nent, BinStats *__restrict__ stats) {
+                                                             uint32_t nent, BinStats *__restrict__ stats,
+                                                             uint32_t *__restrict__ scal) {
   extern __shared__ BinStats lds[];  // nent entries (USE_LDS): a small table leaves room for more workgroups per CU
   if (USE_LDS) {
     for (uint32_t e = threadIdx.x; e < nent; e += kStatsThreads) lds[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u, 0u};
@@ -54,6 +79,7 @@ __global__ __launch_bounds__(kStatsThreads) void k_bin_stats(const uint32_t *__r
   }
   BinStats *tab = USE_LDS ? lds : stats;
   const uint32_t lane = threadIdx.x & (kWave - 1);
+  uint32_t beyond = 0;  // AUTO: largest chromosome id this thread met that the table has no row for
   // A wavefront takes kStatsUnroll x 64 consecutive intervals per trip and has all their loads in flight before it looks
   // at the first (with one chunk per trip the kernel waited for memory: 4 wavefronts per SIMD x 768 bytes each).
   // (wavefront-uniform trip count: the ballots and reductions below need all 64 lanes)
@@ -74,9 +100,13 @@ __global__ __launch_bounds__(kStatsThreads) void k_bin_stats(const uint32_t *__r
 #pragma unroll
     for (int u = 0; u < kStatsUnroll; ++u) {
       const size_t i = i0 + (size_t)u * kWave + lane;
-      const bool valid = i < n;
+      bool valid = i < n;
       const uint32_t lo = lo_[u], hi = hi_[u];
       uint32_t key = 0xFFFFFFFFu, len = 0;
+      if (AUTO && valid && part_[u] >= nent / kLenBins) {  // (the host repeats the statistics with a table of the right size)
+        beyond = max(beyond, part_[u]);
+        valid = false;
+      }
       if (valid) key = part_[u] * kLenBins + len_bin(lo, hi, len);
       // counts: one LDS atomic per interval (lanes of one key serialise on its word, ~30 cycles for the commonest
       // length bin — a scalar loop over the wavefront's distinct keys cost more instructions than that)
@@ -104,6 +134,10 @@ __global__ __launch_bounds__(kStatsThreads) void k_bin_stats(const uint32_t *__r
       }
     }
   }
+  if (AUTO && __ballot(beyond != 0)) {  // (no wavefront comes here when every id has a row: the usual case costs nothing)
+    const uint32_t m = wave_max(beyond);
+    if (lane == 0 && m > peek(&scal[0])) atomicMax(&scal[0], m);
+  }
   if (USE_LDS) {
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < nent; e += kStatsThreads) {
@@ -119,9 +153,10 @@ __global__ __launch_bounds__(kStatsThreads) void k_bin_stats(const uint32_t *__r
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_init_stats(BinStats *stats, uint32_t nent) {
+__global__ __launch_bounds__(kThreads) void k_init_stats(BinStats *stats, uint32_t nent, uint32_t *scal) {
   const uint32_t e = blockIdx.x * kThreads + threadIdx.x;
   if (e < nent) stats[e] = BinStats{0u, 0xFFFFFFFFu, 0u, 0u, 0u};
+  if (scal && e < 4) scal[e] = 0;  // (the build's maxima start at zero)
 }
 
 // workgroup maximum of one value per thread -> ONE atomic per workgroup (every wavefront of a 2 048-workgroup grid
@@ -185,32 +220,56 @@ enum : int { kKeyDense = 0, kKeyLow = 1, kKeySegOfId = 2 };
 
 // kKeyLow also leaves every interval's segment in seg_of[] (append order), so that the second stage — kKeySegOfId:
 // keys[i] = seg_of[ids[i]] — is one gather of one word (recomputing the segment from the gathered columns was four).
+// The key kernel of the first sort (kKeyDense / kKeyLow) walks the sort's own tiles — kTile keys per workgroup of
+// kSortThreads — and leaves the first pass's digit histogram beside the keys (hist0, digit 0 = the keys' low 8 bits): the
+// first pass needs no histogram kernel of its own.
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void k_make_keys(const uint32_t *__restrict__ chrom,
-                                                        const uint8_t *__restrict__ type, uint32_t ntypes,
-                                                        const uint32_t *__restrict__ low,
-                                                        const uint32_t *__restrict__ high, size_t n,
-                                                        const uint32_t *__restrict__ bin2seg,
-                                                        const uint2 *__restrict__ segkey,  // (keybase, base) per segment
-                                                        const uint32_t *__restrict__ ids,   // kKeySegOfId: sorted ids
-                                                        uint32_t *__restrict__ seg_of,      // kKeyLow: out; kKeySegOfId: in
-                                                        uint32_t *__restrict__ keys) {
-  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
+__global__ __launch_bounds__(512) void k_make_keys(const uint32_t *__restrict__ chrom,
+                                                   const uint8_t *__restrict__ type, uint32_t ntypes,
+                                                   const uint32_t *__restrict__ low,
+                                                   const uint32_t *__restrict__ high, size_t n,
+                                                   const uint32_t *__restrict__ bin2seg,
+                                                   const uint2 *__restrict__ segkey,  // (keybase, base) per segment
+                                                   const uint32_t *__restrict__ ids,   // kKeySegOfId: sorted ids
+                                                   uint32_t *__restrict__ seg_of,      // kKeyLow: out; kKeySegOfId: in
+                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ hist0,
+                                                   uint32_t nblocks) {
   if (MODE == kKeySegOfId) {
-    keys[i] = seg_of[ids[i]];
+    const size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+    if (i < n) keys[i] = seg_of[ids[i]];
     return;
   }
-  uint32_t len;
-  const uint32_t lo = low[i];
-  const uint32_t b = len_bin(lo, high[i], len);
-  const uint32_t seg = bin2seg[(size_t)part_of(chrom, type, ntypes, i) * kLenBins + b];
-  if (MODE == kKeyLow) {
-    keys[i] = lo;
-    seg_of[i] = seg;
-  } else {
-    const uint2 k = segkey[seg];
-    keys[i] = k.x + (lo - k.y);
+  __shared__ uint32_t cnt[8][256];  // one table per wavefront
+  for (int w = 0; w < 8; ++w)
+    if (threadIdx.x < 256) cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t *mine = cnt[threadIdx.x >> 6];
+  const size_t base = (size_t)blockIdx.x * 8192;
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const size_t i = base + (size_t)r * 512 + threadIdx.x;
+    if (i < n) {
+      uint32_t len;
+      const uint32_t lo = low[i];
+      const uint32_t b = len_bin(lo, high[i], len);
+      const uint32_t seg = bin2seg[(size_t)part_of(chrom, type, ntypes, i) * kLenBins + b];
+      uint32_t key = lo;
+      if (MODE == kKeyLow) {
+        seg_of[i] = seg;
+      } else {
+        const uint2 k = segkey[seg];
+        key = k.x + (lo - k.y);
+      }
+      keys[i] = key;
+      atomicAdd(&mine[key & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) c += cnt[w][threadIdx.x];
+    hist0[(size_t)threadIdx.x * nblocks + blockIdx.x] = c;
   }
 }
 
@@ -637,34 +696,52 @@ int launch_gather_u8(const uint8_t *d_src, const uint32_t *d_ids, size_t n, size
 int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, uint32_t nparts, BinStats *d_stats, hipStream_t s) {
   const uint32_t nent = nparts * kLenBins;
-  hipLaunchKernelGGL(k_init_stats, dim3(grid_for(nent, kThreads)), dim3(kThreads), 0, s, d_stats, nent);
+  hipLaunchKernelGGL(k_init_stats, dim3(grid_for(nent, kThreads)), dim3(kThreads), 0, s, d_stats, nent, (uint32_t *)nullptr);
   if (n) {
-    const unsigned nb = grid_for(n, kStatsThreads * kStatsUnroll * 2, 2048);
+    const unsigned nb = grid_for(n, kStatsThreads * kStatsUnroll * BIVX_STATS_TRIPS, BIVX_STATS_CAP);
     if (nent <= kStatsLdsEntries)
-      hipLaunchKernelGGL(k_bin_stats<true>, dim3(nb), dim3(kStatsThreads), (size_t)nent * sizeof(BinStats), s, d_chrom,
-                         d_type, ntypes, d_low, d_high, n, nent, d_stats);
+      hipLaunchKernelGGL((k_bin_stats<true, false>), dim3(nb), dim3(kStatsThreads), (size_t)nent * sizeof(BinStats), s, d_chrom,
+                         d_type, ntypes, d_low, d_high, n, nent, d_stats, (uint32_t *)nullptr);
     else
-      hipLaunchKernelGGL(k_bin_stats<false>, dim3(nb), dim3(kStatsThreads), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
-                         nent, d_stats);
+      hipLaunchKernelGGL((k_bin_stats<false, false>), dim3(nb), dim3(kStatsThreads), 0, s, d_chrom, d_type, ntypes, d_low, d_high,
+                         n, nent, d_stats, (uint32_t *)nullptr);
   }
   BIVX_HIP(hipGetLastError());
   return 0;
 }
 
+// No svtypes: statistics of the chromosomes below bin_stats_auto_parts() in one pass without knowing how many there are;
+// d_scal[0] != 0: the largest chromosome id beyond the table (the statistics are then incomplete). d_stats: bin_stats_auto_parts() * kLenBins entries; d_scal[0..3] are zeroed here.
+uint32_t bin_stats_auto_parts() { return kStatsAutoParts; }
+int launch_bin_stats_auto(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n, BinStats *d_stats,
+                          uint32_t *d_scal, hipStream_t s) {
+  const uint32_t nent = bin_stats_auto_parts() * kLenBins;
+  hipLaunchKernelGGL(k_init_stats, dim3(grid_for(nent, kThreads)), dim3(kThreads), 0, s, d_stats, nent, d_scal);
+  if (n) {
+    const unsigned nb = grid_for(n, kStatsThreads * kStatsUnroll * BIVX_STATS_TRIPS, BIVX_STATS_CAP);
+    hipLaunchKernelGGL((k_bin_stats<true, true>), dim3(nb), dim3(kStatsThreads), (size_t)nent * sizeof(BinStats), s, d_chrom,
+                       (const uint8_t *)nullptr, 1u, d_low, d_high, n, nent, d_stats, d_scal);
+  }
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+// d_hist0 (modes 0 and 1): the radix scratch — the first pass's histogram is left there (radix_sort_pairs: hist0_ready)
 int launch_make_keys(int mode, const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, const uint32_t *d_bin2seg, const uint2 *d_segkey,
-                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, hipStream_t s) {
+                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, void *d_hist0, hipStream_t s) {
   if (n == 0) return 0;
-  const dim3 grid(grid_for(n, kThreads)), block(kThreads);
+  const uint32_t nblocks = (uint32_t)((n + kTile - 1) / kTile);
+  uint32_t *hist0 = static_cast<uint32_t *>(d_hist0);
   if (mode == kKeyDense)
-    hipLaunchKernelGGL(k_make_keys<kKeyDense>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
-                       d_segkey, d_ids, d_seg_of, d_keys);
+    hipLaunchKernelGGL(k_make_keys<kKeyDense>, dim3(nblocks), dim3(512), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
+                       d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks);
   else if (mode == kKeyLow)
-    hipLaunchKernelGGL(k_make_keys<kKeyLow>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
-                       d_segkey, d_ids, d_seg_of, d_keys);
+    hipLaunchKernelGGL(k_make_keys<kKeyLow>, dim3(nblocks), dim3(512), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
+                       d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks);
   else
-    hipLaunchKernelGGL(k_make_keys<kKeySegOfId>, grid, block, 0, s, d_chrom, d_type, ntypes, d_low, d_high, n, d_bin2seg,
-                       d_segkey, d_ids, d_seg_of, d_keys);
+    hipLaunchKernelGGL(k_make_keys<kKeySegOfId>, dim3(grid_for(n, 512)), dim3(512), 0, s, d_chrom, d_type, ntypes, d_low,
+                       d_high, n, d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -676,7 +753,7 @@ size_t radix_scratch_bytes(size_t n) {
 }
 
 int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint32_t **vals_alt, size_t n,
-                     int nbits, void *d_scratch, bool vals_are_iota, hipStream_t s) {
+                     int nbits, void *d_scratch, bool vals_are_iota, bool hist0_ready, hipStream_t s) {
   if (n == 0) return 0;
   const uint32_t nblocks = (uint32_t)((n + kTile - 1) / kTile);
   const size_t nh = (size_t)nblocks * kRadix;
@@ -686,7 +763,8 @@ int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint
   bool iota = vals_are_iota;
   // (at least one pass, so that the values exist in memory when they were only implied)
   for (int shift = 0; shift < nbits || iota; shift += kRadixBits) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, n, shift, hist, nblocks);
+    if (!(hist0_ready && shift == 0))  // (the key kernel left the first pass's histogram)
+      hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, n, shift, hist, nblocks);
     hipLaunchKernelGGL(k_radix_rows, dim3(kRadix), dim3(kThreads), 0, s, hist, offs, totals, nblocks);
     if (iota)
       hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, *vals, *keys_alt,

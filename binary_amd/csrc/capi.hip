@@ -49,11 +49,13 @@ struct bivx_index {
     void *p = nullptr;
     size_t cap = 0;
   };
-  DevBuf b_se, b_rec, b_table, b_seg, b_rng;  // what the pointers below point into
+  DevBuf b_se, b_rec, b_table, b_seg;  // what the pointers below point into (b_seg: every small table)
   DevBuf b_keys[2], b_ids[2];                 // sort buffers; the ids end up in one of b_ids and stay there (d_id)
   DevBuf b_misc, b_radix, b_scalar, b_segof;  // build temporaries: statistics, key tables, histogram scratch, maxima,
                                               // every interval's segment (two-sort builds)
   uint32_t *h_scalars = nullptr;              // pinned: the build's few read-backs (max ids, largest cell)
+  void *h_stage = nullptr;                    // pinned, grow-only: the statistics on their way down, the small tables
+  size_t h_stage_cap = 0;                     // of the index on their way up
   // bivx_append_dev copies on the CALLER's stream; the build waits for those copies on its own stream through events
   // instead of synchronising the device
   std::vector<hipEvent_t> ev_pending, ev_free;
@@ -218,7 +220,7 @@ void free_built(bivx_index *idx) {
 }
 
 void release_build_blocks(bivx_index *idx) {
-  for (bivx_index::DevBuf *b : {&idx->b_se, &idx->b_rec, &idx->b_table, &idx->b_seg, &idx->b_rng, &idx->b_keys[0],
+  for (bivx_index::DevBuf *b : {&idx->b_se, &idx->b_rec, &idx->b_table, &idx->b_seg, &idx->b_keys[0],
                                 &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof, &idx->b_selfq}) {
     (void)hipFree(b->p);
     b->p = nullptr;
@@ -235,6 +237,17 @@ int ensure_block(bivx_index::DevBuf &b, size_t bytes) {
   const size_t want = (bytes + 255) & ~(size_t)255;
   BIVX_HIP(hipMalloc(&b.p, want ? want : 256));
   b.cap = want ? want : 256;
+  return 0;
+}
+
+int ensure_stage(bivx_index *idx, size_t bytes) {
+  if (bytes <= idx->h_stage_cap && idx->h_stage) return 0;
+  if (idx->h_stage) (void)hipHostFree(idx->h_stage);
+  idx->h_stage = nullptr;
+  idx->h_stage_cap = 0;
+  const size_t want = std::max<size_t>((bytes + 4095) & ~(size_t)4095, 128 << 10);
+  BIVX_HIP(hipHostMalloc(&idx->h_stage, want, hipHostMallocDefault));
+  idx->h_stage_cap = want;
   return 0;
 }
 
@@ -640,6 +653,7 @@ void bivx_destroy(bivx_index *idx) {
   free_built(idx);
   release_build_blocks(idx);
   if (idx->h_scalars) (void)hipHostFree(idx->h_scalars);
+  if (idx->h_stage) (void)hipHostFree(idx->h_stage);
   for (hipEvent_t ev : idx->ev_pending) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : idx->ev_free) (void)hipEventDestroy(ev);
   (void)hipFree(idx->d_chrom);
@@ -725,16 +739,36 @@ int bivx_build(bivx_index *idx) {
   if (!idx->h_scalars) BIVX_HIP(hipHostMalloc((void **)&idx->h_scalars, 64, hipHostMallocDefault));
   volatile uint32_t *hs = idx->h_scalars;
 
-  // 1. largest chromosome id and svtype, one pass and one read-back. Interval types (bivx_append_typed): the index is
-  // partitioned by (chromosome, svtype) — the "virtual chromosome" chrom * ntypes + svtype takes the chromosome's place
-  // in everything below, so a query that asks for one type walks only that type's segments and pays nothing per
-  // candidate (the svtype filter of mapper.hpp:153-156, done by the layout instead of by three trees)
-  BIVX_TRY(ensure_block(idx->b_scalar, 256));
-  uint32_t *d_scalar = static_cast<uint32_t *>(idx->b_scalar.p);  // [0] max chromosome, [1] max svtype, [2] largest cell
+  // 1. largest chromosome id and svtype. Interval types (bivx_append_typed): the index is partitioned by (chromosome,
+  // svtype) — the "virtual chromosome" chrom * ntypes + svtype takes the chromosome's place in everything below, so a
+  // query that asks for one type walks only that type's segments and pays nothing per candidate (the svtype filter of
+  // mapper.hpp:153-156, done by the layout instead of by three trees).
+  // Without types the statistics pass (2.) finds the largest chromosome id itself: one pass over the columns and one
+  // read-back instead of two, as long as the ids stay below bin_stats_auto_parts().
+  // (b_scalar: [0] max chromosome, [1] max svtype, [2] largest cell, [3] the directory pass's list length; behind them
+  // the one-pass statistics table, so that one copy brings both back)
+  const uint32_t auto_ent = bin_stats_auto_parts() * kLenBins;
+  const size_t auto_bytes = 256 + (size_t)auto_ent * sizeof(BinStats);
+  BIVX_TRY(ensure_block(idx->b_scalar, auto_bytes));
+  uint32_t *d_scalar = static_cast<uint32_t *>(idx->b_scalar.p);
   uint32_t max_chrom = 0, max_type = 0;
-  if (n) {
-    BIVX_HIP(hipMemsetAsync(d_scalar, 0, 16, s));  // the three maxima start at zero
-    BIVX_TRY(launch_max_chrom_type(idx->d_chrom, idx->typed ? idx->d_type : nullptr, n, d_scalar, s));
+  bool have_stats = false;
+  if (n && !idx->typed) {
+    BIVX_TRY(ensure_stage(idx, auto_bytes));
+    BIVX_TRY(launch_bin_stats_auto(idx->d_chrom, idx->d_low, idx->d_high, n,
+                                   reinterpret_cast<BinStats *>(static_cast<char *>(idx->b_scalar.p) + 256), d_scalar, s));
+    BIVX_HIP(hipMemcpyAsync(idx->h_stage, d_scalar, auto_bytes, hipMemcpyDeviceToHost, s));
+    BIVX_HIP(hipStreamSynchronize(s));
+    max_chrom = static_cast<const uint32_t *>(idx->h_stage)[0];
+    if (max_chrom == 0) {  // (no chromosome id beyond the pass's table: the largest is its last non-empty row)
+      have_stats = true;
+      const BinStats *rows = reinterpret_cast<const BinStats *>(static_cast<const char *>(idx->h_stage) + 256);
+      for (uint32_t e = 0; e < auto_ent; ++e)
+        if (rows[e].count) max_chrom = e / kLenBins;
+    }
+  } else if (n) {
+    BIVX_HIP(hipMemsetAsync(d_scalar, 0, 16, s));  // the maxima start at zero
+    BIVX_TRY(launch_max_chrom_type(idx->d_chrom, idx->d_type, n, d_scalar, s));
     BIVX_HIP(hipMemcpyAsync(idx->h_scalars, d_scalar, 8, hipMemcpyDeviceToHost, s));
     BIVX_HIP(hipStreamSynchronize(s));
     max_chrom = hs[0];
@@ -756,22 +790,52 @@ int bivx_build(bivx_index *idx) {
   // 2. per (partition, length bin) statistics -> host
   std::vector<BinStats> st((size_t)nvchrom * kLenBins);
   ClassPlan plan;
-  const size_t stats_bytes = (st.size() * sizeof(BinStats) + 255) & ~(size_t)255;
-  const size_t b2s_bytes = (st.size() * 4 + 255) & ~(size_t)255;
-  if (n) {
-    BIVX_TRY(ensure_block(idx->b_misc, stats_bytes + b2s_bytes));
+  if (have_stats) {
+    std::memcpy(st.data(), static_cast<const char *>(idx->h_stage) + 256, st.size() * sizeof(BinStats));
+  } else if (n) {
+    const size_t bytes = st.size() * sizeof(BinStats);
+    BIVX_TRY(ensure_block(idx->b_misc, bytes));
     BinStats *d_stats = static_cast<BinStats *>(idx->b_misc.p);
     BIVX_TRY(launch_bin_stats(idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, nvchrom, d_stats, s));
-    BIVX_HIP(hipMemcpyAsync(st.data(), d_stats, st.size() * sizeof(BinStats), hipMemcpyDeviceToHost, s));
+    const bool staged = bytes <= ((size_t)1 << 20);  // (through pinned memory: no staging copy inside the runtime)
+    if (staged) BIVX_TRY(ensure_stage(idx, bytes));
+    BIVX_HIP(hipMemcpyAsync(staged ? idx->h_stage : (void *)st.data(), d_stats, bytes, hipMemcpyDeviceToHost, s));
     BIVX_HIP(hipStreamSynchronize(s));
+    if (staged) std::memcpy(st.data(), idx->h_stage, bytes);
   }
   // 3. length classes, segment descriptors
   BIVX_TRY(plan_classes(st, nvchrom, plan));
   const uint32_t nseg = (uint32_t)plan.segs.size();
 
+  // The small tables of the index in ONE device block, put together in pinned memory and uploaded by one copy:
+  //   [SegDesc x nseg | (keybase, base) x nseg | chromosome x nseg | segment ranges | (partition, bin) -> segment]
   // segment ranges per chromosome, one row per interval type: row 0 = every type (the types of a chromosome are
   // neighbours in the segment order), row t = type t, and one all-empty row behind them for types the index lacks
-  std::vector<uint2> rng((size_t)(ntypes + 1) * (nchrom ? nchrom : 1), make_uint2(0u, 0u));
+  const size_t nseg1 = nseg ? nseg : 1;
+  const size_t nrng = (size_t)(ntypes + 1) * (nchrom ? nchrom : 1);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t off_key = up(nseg1 * sizeof(SegDesc));
+  const size_t off_chr = off_key + up(nseg1 * sizeof(uint2));
+  const size_t off_rng = off_chr + up(nseg1 * sizeof(uint32_t));
+  const size_t off_b2s = off_rng + up(nrng * sizeof(uint2));
+  const size_t meta_bytes = off_b2s + up(plan.bin2seg.size() * sizeof(uint32_t));
+  BIVX_TRY(ensure_block(idx->b_seg, meta_bytes));
+  BIVX_TRY(ensure_stage(idx, meta_bytes));
+  char *hm = static_cast<char *>(idx->h_stage), *dm = static_cast<char *>(idx->b_seg.p);
+  idx->d_seg = reinterpret_cast<SegDesc *>(dm);
+  uint2 *d_segkey = reinterpret_cast<uint2 *>(dm + off_key);
+  idx->d_seg_chrom = reinterpret_cast<uint32_t *>(dm + off_chr);
+  idx->d_chrom_rng = reinterpret_cast<uint2 *>(dm + off_rng);
+  uint32_t *d_bin2seg = reinterpret_cast<uint32_t *>(dm + off_b2s);
+  if (nseg) {
+    std::memcpy(hm, plan.segs.data(), (size_t)nseg * sizeof(SegDesc));
+    std::memcpy(hm + off_key, plan.segkey.data(), (size_t)nseg * sizeof(uint2));
+  }
+  uint32_t *seg_chrom = reinterpret_cast<uint32_t *>(hm + off_chr);
+  for (uint32_t c = 0; c < nvchrom; ++c)
+    for (uint32_t k = plan.chrom_seg[c]; k < plan.chrom_seg[c + 1]; ++k) seg_chrom[k] = c / ntypes;
+  uint2 *rng = reinterpret_cast<uint2 *>(hm + off_rng);
+  std::fill(rng, rng + nrng, make_uint2(0u, 0u));
   std::vector<uint32_t> max_segs(ntypes + 1, 0u);
   for (uint32_t c = 0; c < nchrom; ++c) {
     const uint32_t *cs = plan.chrom_seg.data() + (size_t)c * ntypes;
@@ -782,24 +846,8 @@ int bivx_build(bivx_index *idx) {
       max_segs[t] = std::max(max_segs[t], cs[t + 1] - cs[t]);
     }
   }
-  // (descriptors and their sort keys in one block: [SegDesc x nseg | (keybase, base) x nseg])
-  const size_t seg_bytes = ((size_t)(nseg ? nseg : 1) * sizeof(SegDesc) + 255) & ~(size_t)255;
-  BIVX_TRY(ensure_block(idx->b_rng, rng.size() * sizeof(uint2)));
-  // ([SegDesc | (keybase, base) | chromosome] x nseg)
-  BIVX_TRY(ensure_block(idx->b_seg, seg_bytes + (size_t)(nseg ? nseg : 1) * (sizeof(uint2) + sizeof(uint32_t))));
-  idx->d_chrom_rng = static_cast<uint2 *>(idx->b_rng.p);
-  idx->d_seg = static_cast<SegDesc *>(idx->b_seg.p);
-  uint2 *d_segkey = reinterpret_cast<uint2 *>(static_cast<char *>(idx->b_seg.p) + seg_bytes);
-  idx->d_seg_chrom = reinterpret_cast<uint32_t *>(d_segkey + (nseg ? nseg : 1));
-  std::vector<uint32_t> seg_chrom(nseg);
-  for (uint32_t c = 0; c < nvchrom; ++c)
-    for (uint32_t k = plan.chrom_seg[c]; k < plan.chrom_seg[c + 1]; ++k) seg_chrom[k] = c / ntypes;
-  BIVX_HIP(hipMemcpyAsync(idx->d_chrom_rng, rng.data(), rng.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
-  if (nseg) {
-    BIVX_HIP(hipMemcpyAsync(idx->d_seg, plan.segs.data(), (size_t)nseg * sizeof(SegDesc), hipMemcpyHostToDevice, s));
-    BIVX_HIP(hipMemcpyAsync(d_segkey, plan.segkey.data(), (size_t)nseg * sizeof(uint2), hipMemcpyHostToDevice, s));
-    BIVX_HIP(hipMemcpyAsync(idx->d_seg_chrom, seg_chrom.data(), (size_t)nseg * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  }
+  if (!plan.bin2seg.empty()) std::memcpy(hm + off_b2s, plan.bin2seg.data(), plan.bin2seg.size() * sizeof(uint32_t));
+  BIVX_HIP(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, s));
 
   uint32_t max_cell = 0;
   if (n) {
@@ -814,24 +862,22 @@ int bivx_build(bivx_index *idx) {
     BIVX_TRY(ensure_block(idx->b_radix, std::max(radix_scratch_bytes(n), finalize_gap_bytes(plan.nentries, nseg))));
     uint32_t *kA = static_cast<uint32_t *>(idx->b_keys[0].p), *kB = static_cast<uint32_t *>(idx->b_keys[1].p);
     uint32_t *vA = static_cast<uint32_t *>(idx->b_ids[0].p), *vB = static_cast<uint32_t *>(idx->b_ids[1].p);
-    uint32_t *d_bin2seg = reinterpret_cast<uint32_t *>(static_cast<char *>(idx->b_misc.p) + stats_bytes);
-    BIVX_HIP(hipMemcpyAsync(d_bin2seg, plan.bin2seg.data(), plan.bin2seg.size() * 4, hipMemcpyHostToDevice, s));
     const bool dense = plan.key_span <= 0xFFFFFFFFull && !std::getenv("BIVX_BUILD_TWO_STAGE");  // (env: test knob)
     if (dense) {
       BIVX_TRY(launch_make_keys(kBuildKeyDense, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
-                                nullptr, nullptr, kA, s));
-      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for((uint32_t)(plan.key_span - 1)), idx->b_radix.p, true, s));
+                                nullptr, nullptr, kA, idx->b_radix.p, s));
+      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for((uint32_t)(plan.key_span - 1)), idx->b_radix.p, true, true, s));
     } else {
       // (every interval's segment, in append order: the second sort's keys are one gather of it)
       BIVX_TRY(ensure_block(idx->b_segof, n * 4));
       uint32_t *d_seg_of = static_cast<uint32_t *>(idx->b_segof.p);
       BIVX_TRY(launch_make_keys(kBuildKeyLow, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
-                                nullptr, d_seg_of, kA, s));
-      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), idx->b_radix.p, true, s));
+                                nullptr, d_seg_of, kA, idx->b_radix.p, s));
+      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), idx->b_radix.p, true, true, s));
       if (nseg > 1) {
         BIVX_TRY(launch_make_keys(kBuildKeySegOfId, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg,
-                                  d_segkey, vA, d_seg_of, kA, s));
-        BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), idx->b_radix.p, false, s));
+                                  d_segkey, vA, d_seg_of, kA, nullptr, s));
+        BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), idx->b_radix.p, false, false, s));
       }
     }
     idx->d_id = vA;  // (one of the two id blocks; it stays the index's until the next build)

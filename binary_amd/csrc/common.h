@@ -120,6 +120,11 @@ int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void
 // the partition of interval i is chrom[i] * ntypes + type[i] (type == nullptr: chrom[i])
 int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, uint32_t nparts, BinStats *d_stats, hipStream_t s);
+// without svtypes: the statistics of the chromosomes below bin_stats_auto_parts() without knowing their number (the host
+// reads it off the non-empty rows); d_scal[0] != 0 afterwards: the largest id BEYOND the table — the two-step form must run
+uint32_t bin_stats_auto_parts();
+int launch_bin_stats_auto(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n, BinStats *d_stats,
+                          uint32_t *d_scal, hipStream_t s);
 // d_out2[0] = max chromosome id, d_out2[1] = max svtype (d_type may be nullptr); atomic maxima into words the caller zeroed
 int launch_max_chrom_type(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t *d_out2, hipStream_t s);
 // out[i] = src ? src[ids[i]] : 0 for ids[i] < n_src, else 0xFF
@@ -130,13 +135,14 @@ int launch_gather_u8(const uint8_t *d_src, const uint32_t *d_ids, size_t n, size
 enum : int { kBuildKeyDense = 0, kBuildKeyLow = 1, kBuildKeySegOfId = 2 };
 int launch_make_keys(int mode, const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, const uint32_t *d_bin2seg, const uint2 *d_segkey,
-                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, hipStream_t s);
+                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, void *d_hist0, hipStream_t s);
 // stable LSD radix sort of (key, val) pairs on key bits [0, nbits); result ends in (*keys, *vals)
 // (the pointers are swapped with the alt buffers as passes ping-pong). scratch: radix_scratch_bytes(n).
 // vals_are_iota: the values are 0 .. n-1 and need not exist in memory yet (the first pass writes them).
+// hist0_ready: launch_make_keys left the first pass's histogram in d_scratch.
 size_t radix_scratch_bytes(size_t n);
 int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint32_t **vals_alt, size_t n,
-                     int nbits, void *d_scratch, bool vals_are_iota, hipStream_t s);
+                     int nbits, void *d_scratch, bool vals_are_iota, bool hist0_ready, hipStream_t s);
 // se[], rec[] and the bucket directory (with its three spare entries) from the sorted ids (and the sorted dense keys;
 // d_keys == nullptr: low is gathered by id). d_gaps: finalize_gap_bytes() of scratch; *d_ngaps and *d_max_cell must be
 // zero; *d_max_cell receives the largest number of slots any directory cell holds.

@@ -232,3 +232,30 @@ def test_directory_with_long_empty_stretches_and_one_crowded_cell():
         idx.build()
         off, hits = idx.find_overlaps(qlo, qhi)
         _check_csr(off, hits, _brute(chrom, low, high, np.ones(low.size, bool), np.zeros(qlo.size, np.uint32), qlo, qhi), True)
+
+
+@pytest.mark.parametrize("max_chrom", [23, 63, 64, 65, 700])
+def test_untyped_build_with_chromosome_ids_around_the_one_pass_statistics_table(max_chrom):
+    """Without svtypes the statistics pass finds the largest chromosome id itself and has a table for ids below 64; an
+    id beyond it repeats the statistics with the size now known (capi.hip bivx_build steps 1-2). Same hits either way."""
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(max_chrom)
+    n = 60_000
+    chrom = rng.integers(0, max_chrom, n).astype(np.uint32)
+    chrom[n // 2 + 17] = max_chrom                      # the largest id is there once, in the middle of a wavefront
+    low = rng.integers(0, 200_000, n).astype(np.uint32)
+    high = (low + rng.integers(0, 3000, n) * (rng.random(n) < 0.9)).astype(np.uint32)
+    q = 400
+    qc = rng.integers(0, max_chrom + 1, q).astype(np.uint32)
+    qc[:8] = max_chrom
+    qlo = rng.integers(0, 200_000, q).astype(np.uint32)
+    qhi = (qlo + rng.integers(0, 5000, q)).astype(np.uint32)
+    qlo[:8], qhi[:8] = 0, 0xFFFFFFFF
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high, chrom)
+        idx.build()
+        assert idx.stats()["n_chroms"] == max_chrom + 1
+        off, hits = idx.find_overlaps(qlo, qhi, qc)
+    exp = _brute(chrom, low, high, np.ones(n, bool), qc, qlo, qhi)
+    assert exp[0].size == 1
+    _check_csr(off, hits, exp, True)
