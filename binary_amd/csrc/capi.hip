@@ -49,7 +49,7 @@ struct bivx_index {
     void *p = nullptr;
     size_t cap = 0;
   };
-  DevBuf b_se, b_rec, b_table, b_seg;  // what the pointers below point into (b_seg: every small table)
+  DevBuf b_se, b_table, b_seg;  // what the pointers below point into (b_se: se[] and rec[]; b_seg: every small table)
   DevBuf b_keys[2], b_ids[2];                 // sort buffers; the ids end up in one of b_ids and stay there (d_id)
   DevBuf b_misc, b_radix, b_scalar, b_segof;  // build temporaries: statistics, key tables, histogram scratch, maxima,
                                               // every interval's segment (two-sort builds)
@@ -220,7 +220,7 @@ void free_built(bivx_index *idx) {
 }
 
 void release_build_blocks(bivx_index *idx) {
-  for (bivx_index::DevBuf *b : {&idx->b_se, &idx->b_rec, &idx->b_table, &idx->b_seg, &idx->b_keys[0],
+  for (bivx_index::DevBuf *b : {&idx->b_se, &idx->b_table, &idx->b_seg, &idx->b_keys[0],
                                 &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof, &idx->b_selfq}) {
     (void)hipFree(b->p);
     b->p = nullptr;
@@ -856,7 +856,7 @@ int bivx_build(bivx_index *idx) {
     // Otherwise two: by low, then by the segment of the ids as the first sort left them.
     for (int k = 0; k < 2; ++k) {
       BIVX_TRY(ensure_block(idx->b_keys[k], n * 4));
-      BIVX_TRY(ensure_block(idx->b_ids[k], n * 4));
+      BIVX_TRY(ensure_block(idx->b_ids[k], (n + 2) * 4));  // (two spare ids: query lanes read ids two at a time)
     }
     // (histogram scratch of the sort, then the directory pass's short list of long empty stretches)
     BIVX_TRY(ensure_block(idx->b_radix, std::max(radix_scratch_bytes(n), finalize_gap_bytes(plan.nentries, nseg))));
@@ -884,10 +884,11 @@ int bivx_build(bivx_index *idx) {
     // 5. sorted (low, high) pairs and packed (record, id) pairs
     // two spare slots each: query lanes read pairs two at a time (16 B), so the pair holding the last slot may reach
     // one slot past the end
-    BIVX_TRY(ensure_block(idx->b_se, (n + 2) * sizeof(uint2)));
-    BIVX_TRY(ensure_block(idx->b_rec, (n + 2) * sizeof(uint2)));
+    // (one block: k_query_pipe_ms addresses both arrays with 32-bit offsets from one base)
+    const size_t se_bytes = ((n + 2) * sizeof(uint2) + 255) & ~(size_t)255;
+    BIVX_TRY(ensure_block(idx->b_se, 2 * se_bytes));
     idx->d_se = static_cast<uint2 *>(idx->b_se.p);
-    idx->d_rec = static_cast<uint2 *>(idx->b_rec.p);
+    idx->d_rec = reinterpret_cast<uint2 *>(static_cast<char *>(idx->b_se.p) + se_bytes);
     // 6. ... and the bucket directory, by the same pass (+3 spare entries: query lanes read entries four at a time)
     BIVX_TRY(ensure_block(idx->b_table, ((size_t)plan.nentries + 3) * 4));
     idx->d_table = static_cast<uint32_t *>(idx->b_table.p);
@@ -1214,8 +1215,10 @@ const char *bivx_query_kernel_name(const bivx_index *idx, size_t q, uint64_t hit
   IndexView view;
   if (view_with_filter(idx, filter, view) != 0) return "";
   if (pipe_eligible(view, q, hit_capacity, sort_by_id != 0, false)) return "k_query_pipe";
-  if (pipe_dense_eligible(view, q, hit_capacity, sort_by_id != 0, false)) return "k_query_pipe_dense|k_query_fused";
-  return "k_query_fused";
+  const bool ms = pipe_ms_eligible(view, q, hit_capacity, false);
+  if (pipe_dense_eligible(view, q, hit_capacity, sort_by_id != 0, false))
+    return ms ? "k_query_pipe_dense|k_query_pipe_ms" : "k_query_pipe_dense|k_query_fused";
+  return ms ? "k_query_pipe_ms" : "k_query_fused";
 }
 
 int bivx_sort_hits_dev(const bivx_index *idx, const uint64_t *d_offsets, uint32_t *d_hit_ids, size_t q, void *stream) {

@@ -182,6 +182,12 @@ bool pipe_dense_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_i
 int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                             size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
                             int flags, uint32_t seq, hipStream_t s);
+// ... and for everything else that is large: several segments per chromosome, fused filters, many ids per query
+// (skip_seq != 0: launched behind k_query_pipe_dense, returns if that kernel took the launch)
+bool pipe_ms_eligible(const IndexView &v, size_t q, uint64_t cap, bool unordered);
+int launch_query_pipe_ms(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                         size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
+                         int flags, uint32_t skip_seq, hipStream_t s);
 // The index overlapped with itself (queries = its intervals in slot order, results wanted in id order: d_perm = the slots'
 // ids): k_query_pipe_dense writes the lists in slot order into d_tmp_hits and leaves d_counts[id] / d_src_by_id[id] = a
 // list's length / where it begins (cap == 0: the lengths only); launch_permute_lists then gathers list i to d_hits[offsets[i]].

@@ -465,7 +465,10 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
   // ... and so has the case of many ids per query if the batch is position-sorted, which a device-side probe finds out:
   // both kernels are launched, one of them returns at once
   const bool try_dense = !use_pipe && pipe_dense_eligible(v, q, cap, sort_ids, unordered);
-  const size_t per_launch = use_pipe || try_dense ? pipe_tile * max_tiles_pipe : (size_t)max_tiles * kFTile;
+  // ... and so has everything else that is large (several segments per chromosome, fused filters, many ids per query in
+  // any order): a position-sorted batch is left to the dense kernel (which leaves the word for this one to see)
+  const bool use_ms = !use_pipe && pipe_ms_eligible(v, q, cap, unordered);
+  const size_t per_launch = use_pipe || try_dense || use_ms ? pipe_tile * max_tiles_pipe : (size_t)max_tiles * kFTile;
   // caller's workspace: zeroed in front of every launch (ordered output), or once per call (unordered output:
   // the running total lives in it across the call's launches)
   if (!self_clean && unordered && !use_pipe) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));
@@ -473,7 +476,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
     const size_t tile_q = use_pipe ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
     const unsigned tiles = (unsigned)((q1 - q0 + tile_q - 1) / tile_q);
-    const size_t tile_small = use_pipe || try_dense ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
+    const size_t tile_small = use_pipe || try_dense || use_ms ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
     if (!self_clean && (!unordered || use_pipe))
       BIVX_HIP(hipMemsetAsync(d_ws, 0, ((q1 - q0 + tile_small - 1) / tile_small + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
     const dim3 grid(tiles), block(kFThreads);
@@ -489,7 +492,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     // Ordering ids inside the kernel pays while a wavefront's 64 lists fit half its output stage (one round, all
     // lanes busy); the buffer capacity is the only bound on the hit count the host has. Denser results are
     // ordered by k_sort_hits afterwards, whose stage is eight times larger.
-    const bool sort_inside = sort_ids && !unordered && cap <= (uint64_t)kFusedSortMaxAvg * q;
+    const bool sort_inside = sort_ids && !unordered && !use_ms && cap <= (uint64_t)kFusedSortMaxAvg * q;
     static std::atomic<uint32_t> launch_seq{1};
     uint32_t seq = launch_seq.fetch_add(1);
     if (seq == 0) seq = launch_seq.fetch_add(1);  // 0 is what a cleared workspace holds
@@ -502,6 +505,9 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     if (use_pipe) {
       if (int rc = launch_query_pipe(v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, flags,
                                      sort_ids ? seq : 0u, d_counts, d_total, s))
+        return rc;
+    } else if (use_ms) {
+      if (int rc = launch_query_pipe_ms(v, d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, flags, skip_seq, s))
         return rc;
     } else {
 #define BIVX_LAUNCH_FUSED_V(L, FL, SO, MSV, UV)                                                               \

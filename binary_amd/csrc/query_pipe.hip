@@ -84,6 +84,7 @@ struct PipeArgs {
   const uint32_t *perm;
   uint64_t *src_by_id;
   uint32_t *dst_counts;
+  uint32_t rec_delta;  // k_query_pipe_ms: byte distance from se[] to rec[] (one block, below 4 GB)
 };
 constexpr int kFlagSorted = 4;  // k_query_pipe_dense: the batch is known to be position-sorted (no order probe was launched)
 
@@ -1140,6 +1141,390 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
   }
 }
 
+// ---- the same pipeline for EVERYTHING ELSE: several segments per query, fused filters, many ids per query --------------
+// (SV-like length spectra: two or three length classes per chromosome, 8-50 ids per query, windows of 20-150 slots, the
+// longest class not packed. k_query_fused<MS> walks windows beyond 64 slots with the whole wavefront, one query after the
+// other, once to count and once to fill: ~450 vector instructions per query, and that — not memory — is its time:
+// 0.74 ms for 1 M queries of tools/skewed_bench.py 1e5.)
+// Here every lane walks its own windows, sixteen slots per trip (eight 16-byte loads in flight), TWICE: once to count —
+// nothing but the count is kept — and again, when the slice's place in the output is known two iterations later, to put
+// the ids into the wavefront's stage exactly as they sit in the output, from where they leave in whole lines. A pending
+// slice is two registers per lane and no LDS, so the whole LDS of a CU (one workgroup of 1 024 threads, 128 registers)
+// goes to the fifteen stages: 2 432 ids each — a round holds as many consecutive lanes' lists as fit. The second walk
+// finds its lines in L2 (the index of such a workload is a few MB).
+// A slice with a window beyond kMsLaneMax slots, or a list longer than a stage, is counted by the general enumeration
+// and listed for k_fill_slices, as in k_query_pipe.
+#ifndef BIVX_MS_WAVES
+#define BIVX_MS_WAVES 4  // wavefronts per SIMD the kernel is built for: 4 = one workgroup per CU, 128 registers, 160 KB of LDS
+#endif
+constexpr uint32_t kMsKeepN = 16;                                // ids a lane keeps while its slice is pending
+constexpr uint32_t kMsKeepWords = kMsKeepN * kWave;              // ... a wavefront's keep slots, one pending slice
+constexpr uint32_t kMsBuf = 448;      // ids a wavefront lines up per round on their way out
+static_assert(kMsBuf >= 6 * kWave, "the walk's table of window words lives in the buffer");
+constexpr uint32_t kMsStage = 2 * kMsKeepWords + kMsBuf;         // a wavefront's LDS: two pending slices' keep slots + the buffer
+constexpr uint32_t kMsGroupMax = 1024;                           // slots of the longest window a group of lanes walks
+
+// Every lane's hits over all its segments, in index order (segment, slot), by GROUPS of eight lanes, as coop_mask32 does it
+// for the short windows of k_query_pipe: in step j of a round the group fetches sixteen slots — one 128-byte line of
+// records — of the window of its lane j, lane p the p-th pair; the eight steps' loads leave together, so a round is ONE
+// memory round trip for 64 windows, and a window of n slots takes n / 16 rounds. (A lane walking its own window makes
+// eight 16-byte requests per line, and those requests were the kernel's time: 0.23 ms to count tools/skewed_bench.py
+// 1e5; a group walking one window after the other waits 8 x per segment for memory: 0.22 ms.) The owner's window and
+// query travel to its group by ds_swizzle. A step's two ballots carry, in byte g, the hits of group g's even and odd
+// slots; the owner adds their number up; EMIT: every lane ranks its own hits among the group's and stores their ids at
+// the owner's place in the stage (`lpos`: where the lane's list begins there). Packed and plain segments take the same
+// loads (8 bytes per slot from rec[] or se[]) and the same comparison, relative to the window's first cell with the
+// record's 16 + 16 bits or absolute. The directory probe of the next segment is on its way while a segment is walked.
+// `too_long` (counting only): some window is beyond kMsGroupMax slots, the count is meaningless.
+template <int J>
+__device__ __forceinline__ uint32_t of_group_lane(uint32_t x) {  // the value of lane J of this lane's group of eight
+  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x18 | (J << 5));
+}
+
+// MODE: kMsCount — the counts alone; kMsKeep — the counts, and the first kMsKeepN ids of every lane go to its keep slots
+// (`stage`: the wavefront's 64 x kMsKeepN words, slot i of lane l at word i * 64 + l); kMsEmit — the ids go to
+// stage[lpos ..) (the output itself; positions from `limit` on are not written).
+constexpr int kMsCount = 0, kMsKeep = 1, kMsEmit = 2;
+template <int MODE, bool F>
+__device__ __forceinline__ uint32_t group_scan(kargs_t ka, const SegDesc *segs, const Query &q, bool active, uint32_t *stage,
+                                               uint32_t lpos, uint32_t limit, uint32_t lane, uint32_t *tab, bool &too_long) {
+  constexpr bool EMIT = MODE != kMsCount || F;  // ids are wanted (a filter may ask for them)
+  constexpr bool STORE = MODE != kMsCount;
+  too_long = false;
+  uint32_t acc = 0;
+  const uint32_t nseg = active ? q.nseg : 0u;
+  const uint32_t p = lane & 7u, gsh = lane & 0x38u, below = (1u << p) - 1u;
+  IndexView fv;  // what filter_accept reads
+  if (F) {
+    kargs_t pp = fresh(ka);
+    fv.flt_kind = pp->v.flt_kind;
+    fv.flt_dist = pp->v.flt_dist;
+    fv.flt_strand = pp->v.flt_strand;
+    fv.flt_iaux = pp->v.flt_iaux;
+  }
+  struct Probe {
+    uint32_t a, b, cell0;
+    bool packed;
+  };
+  auto probe = [&](uint32_t k) {  // (seg_window's arithmetic, query_device.h; the two loads are not waited for here)
+    Probe w{0u, 0u, 0u, false};
+    if (k < nseg) {
+      const SegDesc d = load_seg(segs + q.s0 + k);
+      const uint32_t x = q.lo > d.maxlen ? q.lo - d.maxlen : 0u;
+      if (!(q.hi < d.base || x > d.last || q.hi < x)) {
+        const uint32_t sh = d.shift & 31u;
+        const uint32_t ca = x <= d.base ? 0u : (x - d.base) >> sh;
+        const uint32_t cb = q.hi >= d.last ? d.ncell : ((q.hi - d.base) >> sh) + 1u;
+        const uint32_t *t = fresh(ka)->v.table + d.table_off;
+        w.a = t[ca];
+        w.b = t[cb];
+        w.cell0 = d.base + (ca << sh);
+        w.packed = (d.shift & kSegPacked) != 0 && ((uint64_t)(cb - ca) << sh) <= 65536ull;
+      }
+    }
+    return w;
+  };
+  // The owners' words sit in a table in LDS (`tab`: 384 words of the wavefront's own), written once per segment: a step
+  // reads its owner's entry at an address that depends on nothing but the lane — eight steps' reads leave back to back,
+  // where eight broadcasts through ds_swizzle were eight waits in a row.
+  //   tabA[l] = (slots | the window begins at the odd slot << 30 | packed << 31,  first even slot)
+  //   tabB[l] = (coordinate the comparison is relative to, q.high, q.low relative to it, -)
+  uint2 *const tabA = reinterpret_cast<uint2 *>(tab);
+  uint4 *const tabB = reinterpret_cast<uint4 *>(tab + 2 * kWave);
+  const char *se_b;
+  const char *id_b;
+  uint32_t rec_delta;
+  {
+    kargs_t pp = fresh(ka);
+    se_b = reinterpret_cast<const char *>(pp->v.se);
+    id_b = reinterpret_cast<const char *>(pp->v.id);
+    rec_delta = pp->a.rec_delta;
+  }
+  Probe nx = probe(0u);
+  for (uint32_t k = 0; __any(k < nseg); ++k) {
+    const Probe w = nx;
+    nx = probe(k + 1u);
+    const uint32_t al = w.a & ~1u;
+    const uint32_t n = w.b > w.a ? w.b - al : 0u;  // slots from the even slot al to the window's end
+    if (MODE != kMsEmit && __any(n > kMsGroupMax)) {
+      too_long = true;
+      return 0u;
+    }
+    {
+      const uint32_t sub = w.packed ? w.cell0 : 0u;
+      wave_sync_lds();  // (the last segment's reads are through)
+      tabA[lane] = make_uint2(n | (w.a & 1u) << 30 | (w.packed ? 1u << 31 : 0u), al);
+      tabB[lane] = make_uint4(sub, q.hi - sub, q.lo > sub ? q.lo - sub : 0u, 0u);
+      wave_sync_lds();
+    }
+    for (uint32_t done = 0; __any(done < n); done += 16u) {  // a round: sixteen more slots of every window
+      uint4 r[8];
+      uint2 ip[8];
+      uint2 was[8];  // (the eight owners' words first: their reads leave together)
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) was[u] = tabA[gsh | u];
+#define BIVX_MS_LOAD(J)                                                                                        \
+  {                                                                                                            \
+    const uint2 wa = was[J];                                                                                   \
+    const uint32_t nn = wa.x & 0x3FFFFFFFu;                                                                    \
+    asm volatile("" : "=v"(r[J].x), "=v"(r[J].y), "=v"(r[J].z), "=v"(r[J].w));  /* (no value: masked below) */ \
+    asm volatile("" : "=v"(ip[J].x), "=v"(ip[J].y));                                                           \
+    if (done + 2u * p < nn) {                                                                                  \
+      const uint32_t off = (((wa.y + done) >> 1) + p) << 4;  /* (at most 2^27 slots: 32-bit byte offsets) */    \
+      r[J] = *reinterpret_cast<const uint4 *>(se_b + (off + ((int)wa.x < 0 ? rec_delta : 0u)));                \
+      if (EMIT && (int)wa.x >= 0) ip[J] = *reinterpret_cast<const uint2 *>(id_b + (off >> 1));                 \
+    }                                                                                                          \
+  }
+#define BIVX_MS_EVAL(J)                                                                                        \
+  {                                                                                                            \
+    const uint2 wa = tabA[gsh | (J)];                                                                          \
+    const uint4 wb = tabB[gsh | (J)];                                                                          \
+    const uint32_t nn = wa.x & 0x3FFFFFFFu, s = done + 2u * p;                                                 \
+    const bool spk = (int)wa.x < 0;                                                                            \
+    const uint32_t smsk = spk ? 0xFFFFu : 0xFFFFFFFFu;                                                         \
+    const bool liveA = s < nn && (s != 0u || (wa.x & (1u << 30)) == 0u), liveB = s + 1u < nn;                  \
+    const uint32_t la = (r[J].x - wb.x) & smsk, lb = (r[J].z - wb.x) & smsk;                                   \
+    const uint32_t ha = spk ? la + (r[J].x >> 16) : r[J].y, hb = spk ? lb + (r[J].z >> 16) : r[J].w;           \
+    const uint32_t ida = spk ? r[J].y : ip[J].x, idb = spk ? r[J].w : ip[J].y;                                 \
+    uint64_t hA, hB;                                                                                           \
+    if (!F) {                                                                                                  \
+      hA = __builtin_amdgcn_uicmp(la, wb.y, 37) & __builtin_amdgcn_uicmp(ha, wb.z, 35) & __ballot(liveA);      \
+      hB = __builtin_amdgcn_uicmp(lb, wb.y, 37) & __builtin_amdgcn_uicmp(hb, wb.z, 35) & __ballot(liveB);      \
+    } else {                                                                                                   \
+      const uint32_t slo = of_group_lane<J>(q.lo), shi = of_group_lane<J>(q.hi), saux = of_group_lane<J>(q.aux); \
+      bool fa = liveA && la <= wb.y && ha >= wb.z, fb = liveB && lb <= wb.y && hb >= wb.z;                     \
+      if (fa) fa = filter_accept(fv, slo, shi, saux, la + wb.x, ha + wb.x, ida);                               \
+      if (fb) fb = filter_accept(fv, slo, shi, saux, lb + wb.x, hb + wb.x, idb);                               \
+      hA = __ballot(fa);                                                                                       \
+      hB = __ballot(fb);                                                                                       \
+    }                                                                                                          \
+    const uint32_t bA = (uint32_t)(hA >> gsh) & 0xFFu, bB = (uint32_t)(hB >> gsh) & 0xFFu;                     \
+    if (STORE) {                                                                                               \
+      const uint32_t spos = of_group_lane<J>(lpos + acc);                                                      \
+      const uint32_t mineA = (bA >> p) & 1u, mineB = (bB >> p) & 1u;                                           \
+      const uint32_t at = spos + (uint32_t)__popc(bA & below) + (uint32_t)__popc(bB & below);                  \
+      if (MODE == kMsKeep) {                                                                                   \
+        if (mineA && at < kMsKeepN) stage[(at << 6) | gsh | (J)] = ida;                                        \
+        if (mineB && at + mineA < kMsKeepN) stage[((at + mineA) << 6) | gsh | (J)] = idb;                      \
+      } else {                                                                                                 \
+        if (mineA && at < limit) stage[at] = ida;                                                              \
+        if (mineB && at + mineA < limit) stage[at + mineA] = idb;                                              \
+      }                                                                                                        \
+    }                                                                                                          \
+    if (p == (J)) acc += (uint32_t)__popc(bA) + (uint32_t)__popc(bB);                                          \
+  }
+      // (eight lines in flight; the filtered variants, which carry the query's own words too, four and four: no scratch)
+      if (!F) {
+        BIVX_MS_LOAD(0) BIVX_MS_LOAD(1) BIVX_MS_LOAD(2) BIVX_MS_LOAD(3)
+        BIVX_MS_LOAD(4) BIVX_MS_LOAD(5) BIVX_MS_LOAD(6) BIVX_MS_LOAD(7)
+        BIVX_MS_EVAL(0) BIVX_MS_EVAL(1) BIVX_MS_EVAL(2) BIVX_MS_EVAL(3)
+        BIVX_MS_EVAL(4) BIVX_MS_EVAL(5) BIVX_MS_EVAL(6) BIVX_MS_EVAL(7)
+      } else {
+        BIVX_MS_LOAD(0) BIVX_MS_LOAD(1) BIVX_MS_LOAD(2) BIVX_MS_LOAD(3)
+        BIVX_MS_EVAL(0) BIVX_MS_EVAL(1) BIVX_MS_EVAL(2) BIVX_MS_EVAL(3)
+        BIVX_MS_LOAD(4) BIVX_MS_LOAD(5) BIVX_MS_LOAD(6) BIVX_MS_LOAD(7)
+        BIVX_MS_EVAL(4) BIVX_MS_EVAL(5) BIVX_MS_EVAL(6) BIVX_MS_EVAL(7)
+      }
+#undef BIVX_MS_LOAD
+#undef BIVX_MS_EVAL
+    }
+  }
+  return acc;
+}
+
+template <bool F>
+__global__ __launch_bounds__(kPThreads, BIVX_MS_WAVES) void k_query_pipe_ms(IndexView v_in, PipeArgs a_in) {
+  (void)v_in;
+  (void)a_in;
+  kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+  __shared__ SegDesc s_seg[kLdsSegs];
+  __shared__ uint2 s_cs[kLdsChroms];
+  __shared__ TileSlot s_slot[kRing];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWorkers][kMsStage];
+  {  // behind k_query_pipe_dense: that kernel did the launch's work if the order probe left this launch's number
+    kargs_t p = fresh(ka);
+    if (p->a.seq != 0 && __hip_atomic_load(reinterpret_cast<const uint32_t *>(p->a.ws + kWsOrder), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT) == p->a.seq)
+      return;
+  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  {
+    kargs_t p = fresh(ka);
+    const uint4 *src = reinterpret_cast<const uint4 *>(p->v.seg);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_seg);
+    const uint32_t nseg2 = p->v.nseg * 2, nchrom = p->v.nchrom;
+    for (uint32_t t = threadIdx.x; t < nseg2; t += kPThreads) dst[t] = src[t];
+    const uint2 *rng = p->v.chrom_rng;
+    for (uint32_t t = threadIdx.x; t < nchrom; t += kPThreads) s_cs[t] = rng[t];
+    if (threadIdx.x < kRing) {
+      s_slot[threadIdx.x].gen_ticket = 0;
+      s_slot[threadIdx.x].gen_base = 0;
+      s_slot[threadIdx.x].arrived = 0;
+      s_slot[threadIdx.x].flushed = 0;
+    }
+  }
+  __syncthreads();
+  const SegDesc *const segs = s_seg;
+  const uint2 *const cs = s_cs;
+  if (wave == kWorkers) {
+    pipe_service_wave(ka, s_slot, lane);
+    return;
+  }
+
+  auto query_of = [&](uint32_t t) {
+    kargs_t p = fresh(ka);
+    const size_t q = p->a.q_begin + (size_t)t * kPTile + threadIdx.x;
+    IndexView w;
+    w.nchrom = p->v.nchrom;
+    w.flt_qaux = p->v.flt_qaux;
+    return load_query<F>(w, cs, p->a.qchrom, p->a.qlow, p->a.qhigh, q, t < p->a.ntiles && q < p->a.q_end);
+  };
+
+  // A pending slice: counted and reported, output deferred by two iterations. Per lane: where its list begins inside the
+  // slice and how long it is; `kept`: every list of the slice is in its lane's keep slots (the usual case while queries
+  // have a few ids each); otherwise the windows are walked again when the slice goes out.
+  struct Pending {
+    bool have, general, kept;
+    uint32_t tile, wtotal;
+    uint64_t x;
+    uint32_t cnt;
+  };
+  Pending pa{false, false, false, 0u, 0u, 0ull, 0u}, pb = pa;
+
+  auto flush = [&](const Pending &pd, uint32_t j) {
+    TileSlot &os = s_slot[j % kRing];
+    lds_wait_eq(&os.gen_base, j + 1);
+    const uint64_t wpos0 = os.base + os.wbase[wave];
+    kargs_t p = fresh(ka);
+    const size_t q_end = p->a.q_end;
+    const size_t q = p->a.q_begin + (size_t)pd.tile * kPTile + threadIdx.x;
+    const uint64_t cap = p->a.cap;
+    if (q < q_end) {
+      uint64_t *off = p->a.offsets;
+      stream_store(off + q, wpos0 + pd.x);
+      if (q == q_end - 1) off[q_end] = wpos0 + pd.x + pd.cnt;
+    }
+    if (cap != 0 && pd.general) {
+      if (lane == 0) {
+        uint64_t *ws = p->a.ws;
+        uint32_t *todo = reinterpret_cast<uint32_t *>(ws + kWsList);
+        todo[atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTodo), 1u)] = pd.tile * 16u + (uint32_t)wave;
+      }
+    } else if (cap != 0 && pd.wtotal != 0) {
+      const uint32_t loff = (uint32_t)pd.x;
+      const uint64_t wp = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)wpos0) |
+                          (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wpos0 >> 32)) << 32;
+      uint32_t *const out = fresh(ka)->a.hits + wp;
+      const uint32_t room = cap > wp ? (cap - wp < 0xFFFFFFFFull ? (uint32_t)(cap - wp) : 0xFFFFFFFFu) : 0u;
+      if (pd.kept) {
+        // out of the keep slots: kMsBuf ids at a time are lined up as they sit in the output and leave in whole lines
+        const uint32_t *const keep = s_stage[wave] + (j & 1u) * kMsKeepWords + lane;
+        uint32_t *const buf = s_stage[wave] + 2 * kMsKeepWords;
+        for (uint32_t r0 = 0; r0 < pd.wtotal; r0 += kMsBuf) {
+          const uint32_t i0 = r0 > loff ? r0 - loff : 0u;                                         // the lane's ids i0 .. i1-1 are in
+          const uint32_t i1 = r0 + kMsBuf < loff + pd.cnt ? (r0 + kMsBuf > loff ? r0 + kMsBuf - loff : 0u) : pd.cnt;  // this round
+          for (uint32_t i = i0; i < i1; ++i) buf[loff + i - r0] = keep[i << 6];
+          wave_sync_lds();
+          const uint32_t nthis = pd.wtotal - r0 < kMsBuf ? pd.wtotal - r0 : kMsBuf;
+          const uint32_t lim = room > r0 ? (room - r0 < nthis ? room - r0 : nthis) : 0u;
+          stage_to_output(buf, out + r0, lim, (uint32_t)lane);
+          wave_sync_lds();
+        }
+      } else {
+        // some list is longer than the keep slots: the windows are walked again, every lane storing its hits straight
+        // to their places — the hits of a round's sixteen slots are neighbours in the output, L2 merges the pieces of a line
+        const Query qy = query_of(pd.tile);
+        bool dummy;
+        (void)group_scan<kMsEmit, F>(ka, segs, qy, pd.cnt != 0, out, loff, room, (uint32_t)lane,
+                                     s_stage[wave] + 2 * kMsKeepWords, dummy);
+      }
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&os.flushed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  lds_wait_eq(&s_slot[0].gen_ticket, 1u);
+  uint32_t tile = __builtin_amdgcn_readfirstlane(s_slot[0].tile);
+  Query qy = query_of(tile);
+  bool keep_mode = true;
+
+  for (uint32_t it = 0;; ++it) {
+    const bool live = tile < A(ntiles);
+    // the slice counted two iterations ago goes out FIRST: its keep slots are the ones this iteration's slice fills
+    if (pb.have) flush(pb, it - 2);
+    if (!live) {
+      if (pa.have) flush(pa, it - 1);
+      break;
+    }
+    bool too_long;
+    uint32_t cnt;
+    // (ids are kept while the wavefront's last slice found room for all of them in its keep slots: with ~50 ids per query
+    // every slice is walked a second time anyway and the first walk need not store anything)
+    const bool no_ids = A(cap) == 0 || !keep_mode;
+    if (no_ids)
+      cnt = group_scan<kMsCount, F>(ka, segs, qy, true, nullptr, 0u, 0u, (uint32_t)lane, s_stage[wave] + 2 * kMsKeepWords, too_long);
+    else
+      cnt = group_scan<kMsKeep, F>(ka, segs, qy, true, s_stage[wave] + (it & 1u) * kMsKeepWords, 0u, 0u, (uint32_t)lane,
+                                   s_stage[wave] + 2 * kMsKeepWords, too_long);
+    if (too_long) {
+      kargs_t p = fresh(ka);
+      IndexView v1;
+      v1.se = p->v.se;
+      v1.rec = p->v.rec;
+      v1.id = p->v.id;
+      v1.table = p->v.table;
+      v1.seg = nullptr;
+      v1.chrom_rng = nullptr;
+      v1.nchrom = 0;
+      v1.nseg = 0;
+      v1.max_segs = p->v.max_segs;
+      v1.nslots = 0;
+      v1.max_cell = 0;
+      v1.flt_kind = p->v.flt_kind;
+      v1.flt_dist = p->v.flt_dist;
+      v1.flt_strand = p->v.flt_strand;
+      v1.flt_qaux = nullptr;
+      v1.flt_iaux = p->v.flt_iaux;
+      v1.err = nullptr;
+      cnt = enumerate_hits<Mode::Count, F, true, kKeep, kRows, false>(v1, segs, qy, nullptr, 0, 0, nullptr);
+    }
+    const uint32_t incl = wave_scan_incl(cnt);
+    // (2^22 hits in one lane would overflow the 32-bit scan: such a slice is summed in 64 bits and left to k_fill_slices)
+    const bool huge = __any(cnt >= (1u << 22));
+    const bool general = too_long || huge;
+    const bool fits = !general && !__any(cnt > kMsKeepN);
+    const bool kept = fits && !no_ids;
+    if (!general) keep_mode = fits;
+    uint32_t wtotal = wave_last(incl);
+    uint64_t wt64 = wtotal, lpos64 = incl - cnt;
+    if (huge) {
+      uint64_t i64 = cnt;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const uint64_t o = __shfl_up((unsigned long long)i64, d, kWave);
+        if (lane >= d) i64 += o;
+      }
+      lpos64 = i64 - cnt;
+      wt64 = __shfl((unsigned long long)i64, kWave - 1, kWave);
+      wtotal = 0xFFFFFFFFu;
+    }
+    TileSlot &sl = s_slot[it % kRing];
+    if (lane == 0) {
+      sl.wsum[wave] = wt64;
+      __hip_atomic_fetch_add(&sl.arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // the next tile's ticket is out already (drawn an iteration ahead): its queries leave now
+    TileSlot &nx = s_slot[(it + 1) % kRing];
+    lds_wait_eq(&nx.gen_ticket, it + 2);
+    const uint32_t ntile = __builtin_amdgcn_readfirstlane(nx.tile);
+    const Query nqy = query_of(ntile);
+    pb = pa;
+    pa = Pending{true, general, kept, tile, wtotal, lpos64, cnt};
+    tile = ntile;
+    qy = nqy;
+  }
+}
+
 // Is the batch in position order? 4096 neighbouring pairs, evenly spread: (chromosome, low) must not descend in more
 // than 2 % of them. Leaves the launch's sequence number in ws[kWsOrder] if so, 0 otherwise.
 __global__ __launch_bounds__(256) void k_probe_order(const uint32_t *__restrict__ qchrom, const uint32_t *__restrict__ qlow,
@@ -1169,7 +1554,7 @@ __global__ __launch_bounds__(256) void k_probe_order(const uint32_t *__restrict_
 // (k_query<Fill>'s, wavefront-cooperative windows included). One work item = one slice (64 queries, one wavefront);
 // the grid is fixed and strides over the items, so the launch needs no host knowledge of the list; the last workgroup
 // to finish clears the count.
-template <bool S>
+template <bool S, bool F = false>
 __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs a) {
   __shared__ SegDesc s_seg[kLdsSegs];
   __shared__ uint2 s_cs[kLdsChroms];
@@ -1188,9 +1573,9 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
     const uint32_t e = todo[w];
     const size_t q = a.q_begin + (size_t)(e >> 4) * kPTile + (size_t)(e & 15u) * kWave + lane;
     const bool valid = q < a.q_end;
-    const Query qy = load_query<false>(v, cs, a.qchrom, a.qlow, a.qhigh, q, valid);
+    const Query qy = load_query<F>(v, cs, a.qchrom, a.qlow, a.qhigh, q, valid);
     const uint64_t pos = !valid ? 0 : a.perm ? a.src_by_id[a.perm[q]] : a.offsets[q];
-    (void)enumerate_hits<Mode::Fill, false>(v, segs, qy, a.hits, pos, a.cap, nullptr);
+    (void)enumerate_hits<Mode::Fill, F>(v, segs, qy, a.hits, pos, a.cap, nullptr);
     if (S) {
       // ascending ids were asked for: the slice's 64 lists are ordered here, where they were just written (asking for
       // the conditional k_sort_hits pass instead would send it over the whole batch for the sake of a few slices)
@@ -1260,7 +1645,55 @@ bool pipe_dense_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_i
   return cap > (uint64_t)6 * q;
 }
 
+// Everything k_query_pipe leaves out — several segments per chromosome, a fused filter, more ids per query than its stages
+// hold — in index order, canonical CSR (ascending ids: k_sort_hits behind it, as behind k_query_fused).
+bool pipe_ms_eligible(const IndexView &v, size_t q, uint64_t cap, bool unordered) {
+  const char *env = std::getenv("BIVX_PIPE");
+  const int mode = env ? std::atoi(env) : 1;
+  if (const char *e = std::getenv("BIVX_PIPE_MS"))  // (0: never — tests compare the two kernels)
+    if (std::atoi(e) == 0) return false;
+  if (!mode || unordered || !fits_lds(v)) return false;
+  if (q < (size_t)768 * 1024 && mode != 2) return false;
+  {  // (se[] and rec[] in one block, 32-bit byte offsets from se[] into both; ids 8 bytes per pair)
+    const ptrdiff_t delta = reinterpret_cast<const char *>(v.rec) - reinterpret_cast<const char *>(v.se);
+    if (v.nslots > (1u << 27) || delta < 0 || (uint64_t)delta + ((uint64_t)v.nslots + 2) * 8 > 0xFFFFFFFFull) return false;
+  }
+  // (positional hotspots: windows beyond kMsGroupMax slots go through the general enumeration twice here)
+  if (v.max_cell > kMsGroupMax / 4 && mode != 2) return false;
+  return v.max_segs > 1 || v.flt_kind != BIVX_FILTER_NONE || cap > (uint64_t)6 * q;
+}
+
 size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }
+
+int launch_query_pipe_ms(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
+                         size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
+                         int flags, uint32_t skip_seq, hipStream_t s) {
+  const unsigned tiles = (unsigned)((q1 - q0 + kPTile - 1) / kPTile);
+  unsigned wgs = 256;
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      wgs = (unsigned)cus * (BIVX_MS_WAVES <= 4 ? 1u : 2u);  // one workgroup per CU: 128 registers, the whole LDS
+    if (const char *e = std::getenv("BIVX_PIPE_WGS")) {
+      const long w = std::atol(e);
+      if (w >= 1 && w <= 65536) wgs = (unsigned)w;
+    }
+  }
+  // (seq: launched behind k_query_pipe_dense, which did the launch's work if the order probe left this number)
+  PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, skip_seq, nullptr, nullptr,
+             nullptr, nullptr, nullptr, (uint32_t)(reinterpret_cast<const char *>(v.rec) - reinterpret_cast<const char *>(v.se))};
+  const dim3 grid(tiles < wgs ? tiles : wgs);
+  if (v.flt_kind != BIVX_FILTER_NONE) {
+    hipLaunchKernelGGL(k_query_pipe_ms<true>, grid, dim3(kPThreads), 0, s, v, a);
+    if (cap != 0) hipLaunchKernelGGL((k_fill_slices<false, true>), dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
+  } else {
+    hipLaunchKernelGGL(k_query_pipe_ms<false>, grid, dim3(kPThreads), 0, s, v, a);
+    if (cap != 0) hipLaunchKernelGGL((k_fill_slices<false, false>), dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
+  }
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
 
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
@@ -1278,7 +1711,7 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
     }
   }
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, sort_seq, d_counts, d_total,
-             nullptr, nullptr, nullptr};
+             nullptr, nullptr, nullptr, 0u};
   if (sort_seq)
     hipLaunchKernelGGL(k_query_pipe<true>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   else
@@ -1307,7 +1740,7 @@ int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const 
     }
   }
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, seq, nullptr, nullptr,
-             nullptr, nullptr, nullptr};
+             nullptr, nullptr, nullptr, 0u};
   hipLaunchKernelGGL(k_probe_order, dim3(1), dim3(256), 0, s, d_qchrom, d_qlow, q0, q1, ws, seq);
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   a.seq = 0;  // (k_fill_slices: index order)
@@ -1411,7 +1844,7 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
   }
   const unsigned tiles = (unsigned)((n + kPTile - 1) / kPTile);
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, 0, n, d_offsets_scratch, d_tmp_hits, cap, ws, tiles, flags, 1u,
-             nullptr, nullptr, d_perm, d_src_by_id, d_counts};
+             nullptr, nullptr, d_perm, d_src_by_id, d_counts, 0u};
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   if (cap != 0) {
     a.seq = 0;  // (k_fill_slices: index order)
