@@ -1185,6 +1185,11 @@ __device__ __forceinline__ uint32_t of_group_lane(uint32_t x) {  // the value of
 // (`stage`: the wavefront's 64 x kMsKeepN words, slot i of lane l at word i * 64 + l); kMsEmit — the ids go to
 // stage[lpos ..) (the output itself; positions from `limit` on are not written).
 constexpr int kMsCount = 0, kMsKeep = 1, kMsEmit = 2;
+#ifdef BIVX_EXP_NOSTORE  // experiment (wrong results): the second walk without its stores
+#define BIVX_EXP_STORE(c) ((c) && limit == 0x12345u)
+#else
+#define BIVX_EXP_STORE(c) (c)
+#endif
 template <int MODE, bool F>
 __device__ __forceinline__ uint32_t group_scan(kargs_t ka, const SegDesc *segs, const Query &q, bool active, uint32_t *stage,
                                                uint32_t lpos, uint32_t limit, uint32_t lane, uint32_t *tab, bool &too_long) {
@@ -1306,9 +1311,10 @@ __device__ __forceinline__ uint32_t group_scan(kargs_t ka, const SegDesc *segs, 
       if (MODE == kMsKeep) {                                                                                   \
         if (mineA && at < kMsKeepN) stage[(at << 6) | gsh | (J)] = ida;                                        \
         if (mineB && at + mineA < kMsKeepN) stage[((at + mineA) << 6) | gsh | (J)] = idb;                      \
-      } else {                                                                                                 \
-        if (mineA && at < limit) stage[at] = ida;                                                              \
-        if (mineB && at + mineA < limit) stage[at + mineA] = idb;                                              \
+      } else { /* (a slice has fewer than 2^28 ids: 32-bit byte offsets from the slice's first output position) */ \
+        char *const ob = reinterpret_cast<char *>(stage);                                                      \
+        if (BIVX_EXP_STORE(mineA && at < limit)) *reinterpret_cast<uint32_t *>(ob + (at << 2)) = ida;          \
+        if (BIVX_EXP_STORE(mineB && at + mineA < limit)) *reinterpret_cast<uint32_t *>(ob + ((at + mineA) << 2)) = idb; \
       }                                                                                                        \
     }                                                                                                          \
     if (p == (J)) acc += (uint32_t)__popc(bA) + (uint32_t)__popc(bB);                                          \
@@ -1645,8 +1651,8 @@ bool pipe_dense_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_i
   return cap > (uint64_t)6 * q;
 }
 
-// Everything k_query_pipe leaves out — several segments per chromosome, a fused filter, more ids per query than its stages
-// hold — in index order, canonical CSR (ascending ids: k_sort_hits behind it, as behind k_query_fused).
+// What k_query_pipe leaves out — several segments per chromosome, a fused filter — in index order, canonical CSR
+// (ascending ids: k_sort_hits behind it, as behind k_query_fused).
 bool pipe_ms_eligible(const IndexView &v, size_t q, uint64_t cap, bool unordered) {
   const char *env = std::getenv("BIVX_PIPE");
   const int mode = env ? std::atoi(env) : 1;
@@ -1660,7 +1666,9 @@ bool pipe_ms_eligible(const IndexView &v, size_t q, uint64_t cap, bool unordered
   }
   // (positional hotspots: windows beyond kMsGroupMax slots go through the general enumeration twice here)
   if (v.max_cell > kMsGroupMax / 4 && mode != 2) return false;
-  return v.max_segs > 1 || v.flt_kind != BIVX_FILTER_NONE || cap > (uint64_t)6 * q;
+  // (many ids per query on ONE length class, queries in any order: k_query_fused is the faster one — config 5 in
+  // generation order 7.7 ms against 8.5 here; tests send it here with BIVX_PIPE=2)
+  return v.max_segs > 1 || v.flt_kind != BIVX_FILTER_NONE || (mode == 2 && cap > (uint64_t)6 * q);
 }
 
 size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }

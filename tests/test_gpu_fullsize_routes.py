@@ -94,7 +94,7 @@ def test_config5_full_size_position_sorted_dense_route(oracle):
         H = int(d_off[-1].item())
         assert 0.7e9 < H < 1.0e9                  # SURVEY §8d expects about 0.81 G
         # many ids per query: both kernels are launched and the order probe gives the batch to the dense one
-        assert idx.query_kernel_name(N, H, False) == "k_query_pipe_dense|k_query_pipe_ms"
+        assert idx.query_kernel_name(N, H, False) == "k_query_pipe_dense|k_query_fused"
         d_hits = torch.full((H,), -1, dtype=torch.int32, device=dev)
         d_off.fill_(-1)
         idx.query_device(d_qlo, d_qhi, d_off, d_hits, qchrom=d_qc, sort_by_id=False)
