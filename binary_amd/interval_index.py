@@ -125,9 +125,10 @@ class IntervalIndex:
     def num_chroms(self) -> int:
         return int(self._L.bivx_num_chroms(self._h))
 
-    def query_kernel_name(self, q: int, hit_capacity: int, sort_by_id: bool = False) -> str:
+    def query_kernel_name(self, q: int, hit_capacity: int, sort_by_id: bool = False, flt=None) -> str:
         """Name of the kernel query_device runs for a batch of q queries into a buffer of hit_capacity ids."""
-        return self._L.bivx_query_kernel_name(self._h, int(q), int(hit_capacity), 1 if sort_by_id else 0, None).decode()
+        return self._L.bivx_query_kernel_name(self._h, int(q), int(hit_capacity), 1 if sort_by_id else 0,
+                                              None if flt is None else C.byref(flt)).decode()
 
     def num_devices(self) -> int:
         return int(self._L.bivx_num_devices(self._h))

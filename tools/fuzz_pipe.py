@@ -30,6 +30,8 @@ for seed in range(S0, S0 + N):
     chrom = rng.integers(0, nchrom, n).astype(np.uint32)
     low = rng.integers(0, L, n).astype(np.uint32)
     high = (low + rng.integers(0, lmax + 1, n)).astype(np.uint32)
+    if rng.random() < 0.4:          # an SV-like length spectrum: several length classes per chromosome, the longest not packed
+        high = (low + np.exp(rng.uniform(np.log(10), np.log(10 ** rng.uniform(3, 6)), n))).astype(np.uint32)
     if rng.random() < 0.2:          # a few inverted records
         k = rng.permutation(n)[: n // 50]
         low[k], high[k] = high[k].copy(), low[k].copy()
@@ -43,6 +45,11 @@ for seed in range(S0, S0 + N):
             sw = rng.permutation(q)[: max(q // 60, 1)]
             p[sw] = p[np.roll(sw, 1)]
         qc, qlo, qhi = qc[p], qlo[p], qhi[p]
+    # interval types (one segment range per chromosome and type) and a query for one type or all; a fused filter
+    typ = rng.integers(1, 4, n).astype(np.uint8) if rng.random() < 0.3 else None
+    qtype = int(rng.integers(0, 5)) if typ is not None else 0
+    from binary_amd import capi
+    fkind = int(rng.choice([capi.FILTER_SV2NL_DUP, capi.FILTER_SV2NL_INV, capi.FILTER_SV2NL_TRA])) if rng.random() < 0.3 else 0
     by_id = bool(rng.random() < 0.4)
     use_ws = bool(rng.random() < 0.3)
     knobs = {}
@@ -51,11 +58,19 @@ for seed in range(S0, S0 + N):
     if rng.random() < 0.3:
         knobs["BIVX_PIPE_WGS"] = str(int(rng.integers(1, 700)))
     with IntervalIndex(0) as idx:
-        idx.insert_node(low, high, chrom)
+        idx.insert_node(low, high, chrom, svtype=typ)
         idx.build()
         d_qlo, d_qhi, d_qc = to(qlo), to(qhi), to(qc)
+        flt = None
+        if fkind:
+            t_qaux = to(rng.integers(0, 12, q).astype(np.uint32))
+            t_iaux = to(rng.integers(0, 12, n).astype(np.uint32))
+            flt = IntervalIndex.device_filter(fkind, int(10 ** rng.uniform(2, 4.5)), bool(rng.random() < 0.5), t_qaux, t_iaux, svtype=qtype)
+        elif qtype:
+            flt = IntervalIndex.type_filter(qtype)
         os.environ["BIVX_PIPE"] = "0"
-        off0 = idx.count_overlaps_device(d_qlo, d_qhi, d_qc)
+        off0 = torch.empty(q + 1, dtype=torch.int64, device=dev)   # (a one-id buffer: the offsets are complete all the same)
+        idx.query_device(d_qlo, d_qhi, off0, torch.empty(1, dtype=torch.int32, device=dev), qchrom=d_qc, flt=flt)
         H = int(off0[-1].item())
         capm = rng.choice(["exact", "small", "zero"], p=[0.7, 0.2, 0.1])
         cap = H if capm == "exact" else (H // 3 if capm == "small" else 0)
@@ -68,8 +83,8 @@ for seed in range(S0, S0 + N):
             off = torch.full((q + 1,), -1, dtype=torch.int64, device=dev)
             hits = torch.full((max(cap, 1),), -1, dtype=torch.int32, device=dev)
             ws = torch.empty(idx.query_workspace_bytes(q), dtype=torch.uint8, device=dev) if use_ws else None
-            name = idx.query_kernel_name(q, max(cap, 1), by_id)
-            idx.query_device(d_qlo, d_qhi, off, hits[:cap] if cap else hits[:0], workspace=ws, qchrom=d_qc, sort_by_id=by_id)
+            name = idx.query_kernel_name(q, max(cap, 1), by_id, flt)
+            idx.query_device(d_qlo, d_qhi, off, hits[:cap] if cap else hits[:0], workspace=ws, qchrom=d_qc, sort_by_id=by_id, flt=flt)
             idx.stream_status()
             res.append((off, hits, name))
         for k in KNOBS:
@@ -86,11 +101,13 @@ for seed in range(S0, S0 + N):
         cnt = (res[0][0][1:] - res[0][0][:-1]).cpu().numpy()
         for i in sel:
             m = (chrom == qc[i]) & (low <= qhi[i]) & (high >= qlo[i])
-            ok = ok and int(m.sum()) == int(cnt[i])
+            if qtype:
+                m &= typ == qtype
+            ok = ok and (bool(fkind) or int(m.sum()) == int(cnt[i]))   # (the filters' own predicates: tests/test_gpu_pipe_ms.py)
         # the index overlapped with itself: bivx_self_overlaps_dev (BIVX_PIPE=2: its fast path whenever the index allows
         # it) against the general call with the appended columns as the batch (BIVX_PIPE=0)
         self_ok = True
-        if n <= 400_000 or big:
+        if (n <= 400_000 or big) and typ is None:
             d_lo, d_hi, d_c = to(low), to(high), to(chrom)
             os.environ["BIVX_PIPE"] = "0"
             soff0 = idx.count_overlaps_device(d_lo, d_hi, d_c)
@@ -112,6 +129,6 @@ for seed in range(S0, S0 + N):
     tag = "ok " if ok else "BAD"
     bad += 0 if ok else 1
     print(f"{tag} seed {seed}: n={n} q={q} chroms={nchrom} L={L} lmax={lmax} H={H} ({H / q:.1f}/query) {order} by_id={by_id} cap={capm} "
-          f"ws={use_ws} {knobs} -> {res[0][2]}", flush=True)
+          f"ws={use_ws} types={typ is not None}/{qtype} filter={fkind} segs={st['n_segments']} {knobs} -> {res[0][2]}", flush=True)
 print(f"{N} sessions, {bad} bad")
 sys.exit(1 if bad else 0)
