@@ -76,6 +76,7 @@ struct bivx_index {
   std::vector<uint32_t> max_segs;      // per row: most segments any one chromosome has
   uint64_t nentries = 0;
   uint32_t max_cell = 0;  // most slots in any directory cell (positional hotspots)
+  uint32_t max_window = 0;  // the planner's estimate of the longest usual window (ClassPlan::max_window)
   size_t built_n = 0;
   double build_ms = 0.0;
   // prefix workspaces of bivx_query_dev calls made without a caller workspace: one per stream (calls on one
@@ -362,6 +363,9 @@ struct ClassPlan {
   // ONE 32-bit key orders by (segment, low); key_span is the sum of the ranges (> 2^32: no such key exists)
   std::vector<uint2> segkey;
   uint64_t key_span = 0;
+  // slots a point query's window is expected to hold in the segment where that is most: count x (longest length + a
+  // directory cell) / coordinate span — what tells k_query_pipe_ms's territory from the wavefront-cooperative walk's
+  uint32_t max_window = 0;
 };
 
 // Chooses, per chromosome, how to cut the 33 length bins into classes. A class is searched with two
@@ -372,6 +376,7 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &pl
   plan.bin2seg.assign((size_t)nchrom * kLenBins, 0xFFFFFFFFu);
   plan.chrom_seg.assign(nchrom + 1, 0);
   plan.segs.clear();
+  plan.max_window = 0;
   uint64_t begin = 0, table_off = 0;
   for (uint32_t c = 0; c < nchrom; ++c) {
     plan.chrom_seg[c] = (uint32_t)plan.segs.size();
@@ -437,6 +442,11 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &pl
       d.shift = sh;
       if (ml <= 0xFFFFu && ninv == 0) d.shift |= kSegPacked;
       d.ncell = (uint32_t)((span >> sh) + 1);
+      {
+        const double est = (double)cnt * ((double)ml + (double)(1ull << sh)) / ((double)span + 1.0);
+        const uint32_t w = est >= (double)cnt ? (uint32_t)cnt : (uint32_t)est;
+        if (w > plan.max_window) plan.max_window = w;
+      }
       if (table_off + d.ncell + 1 > 0xFFFFFFFFull) {
         set_error("bucket directory too large");
         return BIVX_E_RANGE;
@@ -483,6 +493,7 @@ IndexView view_of(const bivx_index *idx, uint32_t svtype = 0) {
   v.max_segs = row < idx->max_segs.size() ? idx->max_segs[row] : 0;
   v.nslots = idx->built_n < 0xFFFFFFFFull ? (uint32_t)idx->built_n : 0xFFFFFFFFu;
   v.max_cell = idx->max_cell;
+  v.max_window = idx->max_window;
   v.flt_kind = BIVX_FILTER_NONE;
   v.flt_dist = 0;
   v.flt_strand = 0;
@@ -904,6 +915,7 @@ int bivx_build(bivx_index *idx) {
   idx->max_segs = std::move(max_segs);
   idx->nentries = plan.nentries;
   idx->max_cell = max_cell;
+  idx->max_window = plan.max_window;
   idx->built = true;
   idx->built_n = n;
   idx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

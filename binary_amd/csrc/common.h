@@ -60,6 +60,7 @@ struct IndexView {
   uint32_t max_segs;          // most segments any one chromosome has (for the selected type)
   uint32_t nslots;            // sorted slots (= intervals built) — saturates at 2^32 - 1
   uint32_t max_cell;          // most slots any directory cell holds (positional hotspots make this large)
+  uint32_t max_window;        // slots a query's window is EXPECTED to hold in the segment where that is most (the planner's estimate)
   // optional post-filter fused into the enumeration (bivx_filter): a candidate must pass it as well
   uint32_t flt_kind;          // BIVX_FILTER_*
   uint32_t flt_dist;

@@ -1486,6 +1486,7 @@ __global__ __launch_bounds__(kPThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Inde
       v1.max_segs = p->v.max_segs;
       v1.nslots = 0;
       v1.max_cell = 0;
+      v1.max_window = 0;
       v1.flt_kind = p->v.flt_kind;
       v1.flt_dist = p->v.flt_dist;
       v1.flt_strand = p->v.flt_strand;
@@ -1665,7 +1666,7 @@ bool pipe_ms_eligible(const IndexView &v, size_t q, uint64_t cap, bool unordered
     if (v.nslots > (1u << 27) || delta < 0 || (uint64_t)delta + ((uint64_t)v.nslots + 2) * 8 > 0xFFFFFFFFull) return false;
   }
   // (positional hotspots: windows beyond kMsGroupMax slots go through the general enumeration twice here)
-  if (v.max_cell > kMsGroupMax / 4 && mode != 2) return false;
+  if ((v.max_cell > kMsGroupMax / 4 || v.max_window > kMsGroupMax / 2) && mode != 2) return false;
   // (many ids per query on ONE length class, queries in any order: k_query_fused is the faster one — config 5 in
   // generation order 7.7 ms against 8.5 here; tests send it here with BIVX_PIPE=2)
   return v.max_segs > 1 || v.flt_kind != BIVX_FILTER_NONE || (mode == 2 && cap > (uint64_t)6 * q);
