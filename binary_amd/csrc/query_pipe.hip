@@ -255,12 +255,15 @@ __device__ __forceinline__ uint32_t coop_mask32(const uint2 *rec, uint32_t *keep
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(W0), 0x18 | ((k) << 5));                          \
     const uint32_t s1 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w.base, 0x18 | ((k) << 5));                       \
     const uint32_t s2 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w2, 0x18 | ((k) << 5));                           \
-    const bool act = p < ((s0 >> 27) & 15u);                                                                          \
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);                                                                             \
-    if (act) r = *reinterpret_cast<const uint4 *>(rb + (((s0 & 0x7FFFFFFu) + p) << 4));                              \
+    /* (the lanes whose pair lies in the window, as a lane mask straight from the comparison; what a lane that loads    \
+       nothing has in its registers is evaluated like the rest and masked off by it) */                               \
+    const uint32_t np_ = (s0 >> 27) & 15u;                                                                            \
+    const uint64_t live = __builtin_amdgcn_uicmp(p, np_, 36);                                                         \
+    uint4 r;                                                                                                          \
+    asm volatile("" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w));                                                    \
+    if (p < np_) r = *reinterpret_cast<const uint4 *>(rb + (((s0 & 0x7FFFFFFu) + p) << 4));                           \
     const uint32_t sql = (s2 & 0xFFFFu) | (s0 >> 31) << 16, sqh = s2 >> 16;                                           \
     const uint32_t la = (r.x - s1) & 0xFFFFu, lb = (r.z - s1) & 0xFFFFu;                                              \
-    const uint64_t live = __ballot(act);                                                                              \
     const uint64_t hA = __builtin_amdgcn_uicmp(la, sqh, 37) & __builtin_amdgcn_uicmp(la + (r.x >> 16), sql, 35) & live; \
     const uint64_t hB = __builtin_amdgcn_uicmp(lb, sqh, 37) & __builtin_amdgcn_uicmp(lb + (r.z >> 16), sql, 35) & live; \
     const uint32_t bA = (uint32_t)(hA >> gsh) & 0xFFu, bB = (uint32_t)(hB >> gsh) & 0xFFu;                            \
