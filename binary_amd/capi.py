@@ -11,7 +11,7 @@ from ._build import LIB_PATH
 
 BIVX_NO_HIT = 0xFFFFFFFF
 E_INVALID, E_HIP, E_NOMEM, E_STATE, E_RANGE, E_TIMEOUT = -1, -2, -3, -4, -5, -6
-ABI_VERSION = 0x00020001
+ABI_VERSION = 0x00020002
 
 EXPORTS = (
     "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_create_sharded", "bivx_num_devices", "bivx_device_of_chrom", "bivx_destroy", "bivx_device", "bivx_append",
@@ -19,7 +19,7 @@ EXPORTS = (
     "bivx_get_intervals", "bivx_count", "bivx_fill", "bivx_count_dev",
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
     "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f", "bivx_query_dev_s", "bivx_query_dev_u",
-    "bivx_find_overlaps", "bivx_free", "bivx_self_overlaps_dev", "bivx_stream_status", "bivx_query_kernel_name", "bivx_debug_corrupt_workspace",
+    "bivx_find_overlaps", "bivx_free", "bivx_self_overlaps_dev", "bivx_stream_status", "bivx_query_kernel_name", "bivx_debug_corrupt_workspace", "bivx_release_pooled",
 )
 
 

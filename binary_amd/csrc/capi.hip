@@ -568,6 +568,97 @@ int check_query_args(const bivx_index *idx, const void *qlow, const void *qhigh,
 
 }  // namespace
 
+namespace {
+
+// Single-device index objects handed back by bivx_destroy, waiting for the next bivx_create (include/bivx.h,
+// bivx_release_pooled). Never torn down at exit: the HIP runtime may be gone by then.
+struct IndexPool {
+  std::mutex m;
+  std::vector<bivx_index *> idle;
+};
+IndexPool &index_pool() {
+  static IndexPool *p = new IndexPool();
+  return *p;
+}
+size_t env_size(const char *name, size_t dflt) {
+  const char *e = std::getenv(name);
+  if (!e) return dflt;
+  const long long v = std::atoll(e);
+  return v < 0 ? dflt : (size_t)v;
+}
+
+size_t device_bytes_of(const bivx_index *idx) {
+  size_t b = idx->cap * 13 + idx->cache_bytes + idx->b_selfq.cap;
+  for (const bivx_index::DevBuf *d : {&idx->b_se, &idx->b_table, &idx->b_seg, &idx->b_keys[0], &idx->b_keys[1], &idx->b_ids[0],
+                                      &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof})
+    b += d->cap;
+  for (auto &kv : idx->ws_of_stream) b += fused_workspace_bytes(0) + kv.second.self_cap;
+  return b;
+}
+
+void destroy_now(bivx_index *idx) {
+  DeviceGuard g(idx->device);
+  if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+  (void)hipDeviceSynchronize();
+  for (auto &kv : idx->ws_of_stream) {
+    (void)hipFree(kv.second.p);
+    (void)hipFree(kv.second.self_p);
+  }
+  if (idx->h_err) (void)hipHostFree(idx->h_err);
+  for (auto &m : idx->mailboxes) (void)hipHostFree(m.first);
+  idx->mailboxes.clear();
+  drop_block_cache(idx);
+  free_built(idx);
+  release_build_blocks(idx);
+  if (idx->h_scalars) (void)hipHostFree(idx->h_scalars);
+  if (idx->h_stage) (void)hipHostFree(idx->h_stage);
+  for (hipEvent_t ev : idx->ev_pending) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : idx->ev_free) (void)hipEventDestroy(ev);
+  (void)hipFree(idx->d_chrom);
+  (void)hipFree(idx->d_low);
+  (void)hipFree(idx->d_high);
+  (void)hipFree(idx->d_type);
+  if (idx->stream) (void)hipStreamDestroy(idx->stream);
+  delete idx;
+}
+
+// empties the index as bivx_clear does and parks it; false: it cannot be kept (the caller destroys it)
+bool park(bivx_index *idx) {
+  const size_t slots = env_size("BIVX_INDEX_POOL", 4);
+  if (slots == 0 || device_bytes_of(idx) > (env_size("BIVX_INDEX_POOL_MB", 4096) << 20)) return false;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return false;
+  // nothing of the last owner's may still be running on the blocks the next owner will write
+  if (hipStreamSynchronize(idx->stream) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+  {
+    volatile uint32_t *e = idx->h_err;
+    if (e[kErrTimeout] | e[kErrWorkspace]) return false;  // (a failed launch may have left a workspace dirty)
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    for (auto &kv : idx->ws_of_stream)
+      if (kv.second.needs_reset) return false;
+  }
+  for (hipEvent_t ev : idx->ev_pending) idx->ev_free.push_back(ev);
+  idx->ev_pending.clear();
+  if (idx->typed && idx->d_type && idx->n) {
+    if (hipMemsetAsync(idx->d_type, 0, idx->n, idx->stream) != hipSuccess || hipStreamSynchronize(idx->stream) != hipSuccess)
+      return false;
+  }
+  free_built(idx);
+  idx->n = 0;
+  idx->typed = false;
+  idx->built_n = 0;
+  idx->build_ms = 0.0;
+  idx->max_cell = idx->max_window = 0;
+  idx->errors_reported.store(0);
+  IndexPool &p = index_pool();
+  std::lock_guard<std::mutex> lock(p.m);
+  if (p.idle.size() >= slots) return false;
+  p.idle.push_back(idx);
+  return true;
+}
+
+}  // namespace
+
 extern "C" {
 
 uint32_t bivx_abi_version(void) { return BIVX_ABI_VERSION; }
@@ -587,6 +678,16 @@ int bivx_create(bivx_index **out, int device) {
   if (device < 0 || device >= ndev) {
     set_error("bivx_create: device %d out of range [0, %d)", device, ndev);
     return BIVX_E_INVALID;
+  }
+  {  // an index object a bivx_destroy left for this device?
+    IndexPool &p = index_pool();
+    std::lock_guard<std::mutex> lock(p.m);
+    for (size_t k = p.idle.size(); k-- > 0;)
+      if (p.idle[k]->device == device) {
+        *out = p.idle[k];
+        p.idle.erase(p.idle.begin() + (ptrdiff_t)k);
+        return 0;
+      }
   }
   bivx_index *idx = new (std::nothrow) bivx_index();
   if (!idx) {
@@ -650,29 +751,17 @@ void bivx_destroy(bivx_index *idx) {
     delete idx;
     return;
   }
-  DeviceGuard g(idx->device);
-  if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-  (void)hipDeviceSynchronize();
-  for (auto &kv : idx->ws_of_stream) {
-    (void)hipFree(kv.second.p);
-    (void)hipFree(kv.second.self_p);
+  if (!park(idx)) destroy_now(idx);
+}
+
+void bivx_release_pooled(void) {
+  std::vector<bivx_index *> all;
+  {
+    IndexPool &p = index_pool();
+    std::lock_guard<std::mutex> lock(p.m);
+    all.swap(p.idle);
   }
-  if (idx->h_err) (void)hipHostFree(idx->h_err);
-  for (auto &m : idx->mailboxes) (void)hipHostFree(m.first);
-  idx->mailboxes.clear();
-  drop_block_cache(idx);
-  free_built(idx);
-  release_build_blocks(idx);
-  if (idx->h_scalars) (void)hipHostFree(idx->h_scalars);
-  if (idx->h_stage) (void)hipHostFree(idx->h_stage);
-  for (hipEvent_t ev : idx->ev_pending) (void)hipEventDestroy(ev);
-  for (hipEvent_t ev : idx->ev_free) (void)hipEventDestroy(ev);
-  (void)hipFree(idx->d_chrom);
-  (void)hipFree(idx->d_low);
-  (void)hipFree(idx->d_high);
-  (void)hipFree(idx->d_type);
-  if (idx->stream) (void)hipStreamDestroy(idx->stream);
-  delete idx;
+  for (bivx_index *idx : all) destroy_now(idx);
 }
 
 int bivx_device(const bivx_index *idx) { return idx ? idx->device : -1; }

@@ -51,7 +51,7 @@ typedef enum bivx_status {
 #define BIVX_NO_HIT 0xFFFFFFFFu
 
 /* ABI version of this header: major << 16 | minor. */
-#define BIVX_ABI_VERSION 0x00020001u
+#define BIVX_ABI_VERSION 0x00020002u
 uint32_t bivx_abi_version(void);
 const char *bivx_last_error(void);
 
@@ -61,6 +61,12 @@ const char *bivx_last_error(void);
 int bivx_create(bivx_index **out, int device);
 void bivx_destroy(bivx_index *idx);
 int bivx_device(const bivx_index *idx);
+/* The reference builds a tree per task and drops it (mapper.hpp:147-162,199). A destroyed single-device index is therefore
+ * kept — emptied, with its stream and its grow-only device and pinned blocks — for the next bivx_create on the same
+ * device: a handful of objects per process (BIVX_INDEX_POOL, default 4; 0 = none), none above BIVX_INDEX_POOL_MB of
+ * device memory (default 4096). hipFree / hipHostFree / hipStreamDestroy are otherwise 2 ms of a 2.6 ms
+ * create - fill - build - query - drop cycle of a million intervals. This frees what is kept. */
+void bivx_release_pooled(void);
 
 /* ---- several GPUs of one node behind one handle ------------------------------------------------------
  * replaces: the reference's only decomposition, one task per chromosome on a thread pool

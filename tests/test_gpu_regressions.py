@@ -259,3 +259,57 @@ def test_untyped_build_with_chromosome_ids_around_the_one_pass_statistics_table(
     exp = _brute(chrom, low, high, np.ones(n, bool), qc, qlo, qhi)
     assert exp[0].size == 1
     _check_csr(off, hits, exp, True)
+
+
+def test_destroyed_index_objects_are_reused_by_the_next_create(monkeypatch):
+    """bivx_destroy parks a single-device index (emptied; stream, device and pinned blocks kept) for the next bivx_create
+    (include/bivx.h, bivx_release_pooled): a tree per task, built, queried and dropped, as the reference does
+    (mapper.hpp:147-162,199). The next owner must see an empty index: no intervals, no types, no error history — and
+    the same answers as from a fresh object."""
+    import ctypes as C
+    from binary_amd import IntervalIndex, capi
+    L = capi.load()
+    L.bivx_release_pooled.restype = None
+    L.bivx_release_pooled()
+    rng = np.random.default_rng(11)
+
+    def task(n, typed, nchrom):
+        chrom = rng.integers(0, nchrom, n).astype(np.uint32)
+        low = rng.integers(0, 3_000_000, n).astype(np.uint32)
+        high = (low + rng.integers(0, 5000, n)).astype(np.uint32)
+        typ = rng.integers(1, 4, n).astype(np.uint8) if typed else None
+        qc = rng.integers(0, nchrom, 500).astype(np.uint32)
+        qlo = rng.integers(0, 3_000_000, 500).astype(np.uint32)
+        qhi = (qlo + rng.integers(0, 4000, 500)).astype(np.uint32)
+        return chrom, low, high, typ, qc, qlo, qhi
+
+    def run(t):
+        chrom, low, high, typ, qc, qlo, qhi = t
+        with IntervalIndex(0) as idx:
+            st0 = idx.stats()
+            assert st0["n_intervals"] == 0 and st0["prefix_timeouts"] == 0 and idx.num_types() == 1
+            idx.insert_node(low, high, chrom, svtype=typ)
+            idx.build()
+            out = [idx.find_overlaps(qlo, qhi, qc)]
+            if typ is not None:
+                out.append(idx.find_overlaps(qlo, qhi, qc, svtype=2))
+            handle = idx._h.value if hasattr(idx._h, "value") else int(idx._h)
+        return out, handle
+
+    tasks = [task(90_000, True, 5), task(20_000, False, 2), task(150_000, False, 9), task(30_000, True, 3)]
+    pooled, handles = [], []
+    for t in tasks:                       # every task's index is the previous task's object
+        o, h = run(t)
+        pooled.append(o)
+        handles.append(h)
+    assert len(set(handles)) == 1
+    monkeypatch.setenv("BIVX_INDEX_POOL", "0")
+    L.bivx_release_pooled()
+    for t, o in zip(tasks, pooled):       # fresh objects: the same answers
+        f, _ = run(t)
+        for (a_off, a_hits), (b_off, b_hits) in zip(o, f):
+            assert np.array_equal(a_off, b_off) and np.array_equal(a_hits, b_hits)
+        exp = _brute(t[0], t[1], t[2], np.ones(t[1].size, bool), t[4], t[5], t[6])
+        _check_csr(o[0][0], o[0][1], exp, True)
+        if t[3] is not None:
+            _check_csr(o[1][0], o[1][1], _brute(t[0], t[1], t[2], t[3] == 2, t[4], t[5], t[6]), True)
