@@ -73,6 +73,9 @@ def test_sv_like_spectra_equal_the_fused_kernel_and_the_predicate(oracle, maxlen
             assert idx.query_kernel_name(q, H, False) == "k_query_pipe_ms"
         with _env(BIVX_PIPE=0):
             assert idx.query_kernel_name(q, H, False) == "k_query_fused"
+        # default routing: batches of 0.8 M queries and more on an index whose windows the kernel walks itself
+        assert idx.query_kernel_name(1_000_000, H, False) == ("k_query_pipe_ms" if maxlen <= 1e6 else "k_query_fused")
+        assert idx.query_kernel_name(100_000, H, False) == "k_query_fused"
         for by_id in (False, True):
             off_p, hits_p = _run(idx, 2, dq, dq, None, H, by_id)
             off_f, hits_f = _run(idx, 0, dq, dq, None, H, by_id)
