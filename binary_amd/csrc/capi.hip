@@ -372,7 +372,18 @@ struct ClassPlan {
 // directory lookups (cost kSearchCost) and scans about density * max_len candidates that cannot be hits;
 // a tiny dynamic programme over the non-empty bins minimises the sum. Uniform short intervals end up in
 // one class; a few chromosome-scale intervals get a class of their own instead of widening every window.
-int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &plan) {
+int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, size_t n_total, ClassPlan &plan) {
+  // Directory density: at most cnt / slots_per_cell cells per segment, i.e. slots_per_cell .. 2 x slots_per_cell slots per
+  // cell. A finer directory means fewer candidate slots per window and twice the directory: it pays once the index is
+  // past what an XCD's L2 holds anyway (config 3, 10 M intervals: 0.306 -> 0.293 ms per batch with 1 instead of 2; config
+  // 2, 1 M intervals: 43.8 -> 46.2 us). BIVX_SLOTS_PER_CELL overrides.
+  const uint64_t slots_per_cell = [&]() -> uint64_t {
+    if (const char *e = std::getenv("BIVX_SLOTS_PER_CELL")) {
+      const long v = std::atol(e);
+      return (uint64_t)(v < 1 ? 1 : v);
+    }
+    return n_total >= ((size_t)4 << 20) ? 1u : 2u;
+  }();
   plan.bin2seg.assign((size_t)nchrom * kLenBins, 0xFFFFFFFFu);
   plan.chrom_seg.assign(nchrom + 1, 0);
   plan.segs.clear();
@@ -430,13 +441,7 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, ClassPlan &pl
       d.last = mx;
       d.maxlen = ml;
       const uint64_t span = (uint64_t)mx - mn;
-      // directory density: at most cnt / kSlotsPerCell cells, i.e. kSlotsPerCell .. 2*kSlotsPerCell slots per cell
-      static const uint64_t kSlotsPerCell = [] {
-        const char *e = std::getenv("BIVX_SLOTS_PER_CELL");  // tuning knob; default 2
-        const long v = e ? std::atol(e) : 2;
-        return (uint64_t)(v < 1 ? 1 : v);
-      }();
-      const uint64_t target = cnt / kSlotsPerCell > 1 ? cnt / kSlotsPerCell : 1;
+      const uint64_t target = cnt / slots_per_cell > 1 ? cnt / slots_per_cell : 1;  // (two and four cells per slot: 0.315, 0.369 ms)
       uint32_t sh = 0;
       while (sh < 31 && (span >> sh) + 1 > target) ++sh;
       d.shift = sh;
@@ -904,7 +909,7 @@ int bivx_build(bivx_index *idx) {
     if (staged) std::memcpy(st.data(), idx->h_stage, bytes);
   }
   // 3. length classes, segment descriptors
-  BIVX_TRY(plan_classes(st, nvchrom, plan));
+  BIVX_TRY(plan_classes(st, nvchrom, n, plan));
   const uint32_t nseg = (uint32_t)plan.segs.size();
 
   // The small tables of the index in ONE device block, put together in pinned memory and uploaded by one copy:
