@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         if (counts) counts[q] = c;
         if (q == q_end - 1) *(counts ? p->a.total_out : off + q_end) = wpos0 + lp + c;
       }
-      if (lane == 0) {
+      if (lane == 0 && p->a.cap != 0) {  // (no buffer, no ids to fill in: k_fill_slices is not even launched then)
         uint64_t *ws = p->a.ws;
         uint32_t *todo = reinterpret_cast<uint32_t *>(ws + kWsList);
         todo[atomicAdd(reinterpret_cast<unsigned int *>(ws + kWsTodo), 1u)] = pd.tile * 16u + (uint32_t)wave;
@@ -1728,10 +1728,13 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
     hipLaunchKernelGGL(k_query_pipe<true>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   else
     hipLaunchKernelGGL(k_query_pipe<false>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
-  if (sort_seq)
+  if (cap == 0) {
+    // a pure count: nothing is listed, nothing to fill in (the launch, empty as it usually is, costs 4.8 us)
+  } else if (sort_seq) {
     hipLaunchKernelGGL(k_fill_slices<true>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
-  else
+  } else {
     hipLaunchKernelGGL(k_fill_slices<false>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
+  }
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -1756,7 +1759,7 @@ int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const 
   hipLaunchKernelGGL(k_probe_order, dim3(1), dim3(256), 0, s, d_qchrom, d_qlow, q0, q1, ws, seq);
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   a.seq = 0;  // (k_fill_slices: index order)
-  hipLaunchKernelGGL(k_fill_slices<false>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
+  if (cap != 0) hipLaunchKernelGGL(k_fill_slices<false>, dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
