@@ -1233,7 +1233,8 @@ int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_of
   // per stream: [counts u32 x n | scan scratch | list sources u64 x n | the lists in slot order u32 x capacity]
   const size_t cnt_bytes = (n * 4 + 255) & ~(size_t)255, scan_bytes = (scan_scratch_bytes(n) + 255) & ~(size_t)255;
   const size_t src_bytes = hit_capacity ? (n * 8 + 255) & ~(size_t)255 : 0;
-  const size_t self_bytes = cnt_bytes + scan_bytes + src_bytes + (size_t)hit_capacity * 4;
+  // (+ 256: k_permute_lines reads the lists in whole aligned lines, the last one may reach past the last id)
+  const size_t self_bytes = cnt_bytes + scan_bytes + src_bytes + (size_t)hit_capacity * 4 + 256;
   {
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     auto it = idx->ws_of_stream.find(s);

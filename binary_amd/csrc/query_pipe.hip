@@ -1837,6 +1837,94 @@ __global__ __launch_bounds__(kQThreads) void k_permute_lists(const uint64_t *__r
   }
 }
 
+// The same, a line at a time (the default; k_permute_lists keeps wavefronts with very long lists). Random 128-byte lines
+// come out of HBM at 45-50 G per second when a group of eight lanes asks for one (tools/ub_gather.hip, tables of 1-8
+// GB); the element-by-element gather above reaches 23 G. Here the wavefront's 64 lists — one contiguous piece of the
+// output — are put together in LDS: in step j of a round, group g fetches one aligned 128-byte line of the list of its
+// lane j (lane p the p-th 16 bytes) and every lane drops the up to four ids of its 16 bytes that belong to the list at
+// their places in the piece; the eight steps' loads leave together, a list of k lines takes k rounds. The piece then
+// leaves in whole lines. Pieces beyond the buffer go in runs of consecutive lists that fit.
+#ifndef BIVX_PERM_BUF
+#define BIVX_PERM_BUF 1536
+#endif
+constexpr uint32_t kPermBuf = BIVX_PERM_BUF;      // ids a wavefront puts together at a time (6 KB: 1024 / 1536 / 2048 / 3072 / 4096 -> 5.11 / 4.48 / 4.59 / 4.84 / 5.65 ms at config 5)
+constexpr uint32_t kPermListMax = 1024;  // a wavefront with a longer list takes the element-wise way
+
+__global__ __launch_bounds__(kQThreads) void k_permute_lines(const uint64_t *__restrict__ offsets,
+                                                             const uint64_t *__restrict__ src, const uint32_t *__restrict__ tmp,
+                                                             uint32_t *__restrict__ hits, size_t n, uint64_t cap) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[kQWaves][kPermBuf];
+  __shared__ uint4 s_tab[kQWaves][kWave];  // per list: (source low, source high, length, place in the run)
+  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * kQThreads + threadIdx.x;
+  const uint64_t o0 = offsets[i < n ? i : n], o1 = offsets[i < n ? i + 1 : n];
+  const uint64_t wb = __shfl((unsigned long long)o0, 0, kWave);  // the wavefront's piece of the output: [wb, we)
+  const uint64_t we = __shfl((unsigned long long)o1, kWave - 1, kWave);
+  const uint64_t sp = i < n && o1 > o0 ? src[i] : 0ull;
+  if (we - wb > 0xFFFFFFFFull || __any(o1 - o0 > kPermListMax)) {
+    // (rare: the element-wise gather of k_permute_lists, one list per lane)
+    if (i < n)
+      for (uint64_t k = 0; k < o1 - o0; ++k)
+        if (o0 + k < cap && sp + k < cap) hits[o0 + k] = tmp[sp + k];
+    return;
+  }
+  const uint32_t len = (uint32_t)(o1 - o0), loff = (uint32_t)(o0 - wb);
+  const uint32_t p = lane & 7u, gsh = lane & 0x38u;
+  uint32_t *const buf = s_buf[wave];
+  uint32_t first = 0;
+  while (first < (uint32_t)kWave) {
+    // a run of consecutive lists that fit the buffer together (a list fits by itself)
+    const uint32_t base = __shfl(loff, (int)first, kWave);
+    const uint64_t fit = __ballot(lane >= first && loff + len - base <= kPermBuf);
+    const uint64_t nofit = ~fit & (~0ull << first);
+    const uint32_t next = nofit ? (uint32_t)__ffsll((long long)nofit) - 1u : (uint32_t)kWave;
+    const bool mine = lane >= first && lane < next && len != 0;
+    // the list's first line (32 ids) and how many it spans
+    const uint32_t shift = (uint32_t)sp & 31u;
+    const uint32_t nlines = mine ? (shift + len + 31u) >> 5 : 0u;
+    s_tab[wave][lane] = make_uint4((uint32_t)sp, (uint32_t)(sp >> 32), mine ? len : 0u, loff - base);
+    wave_sync_lds();
+    for (uint32_t r = 0; __any(r < nlines); ++r) {
+      uint4 v[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint4 t = s_tab[wave][gsh | j];
+        const uint64_t s0 = (uint64_t)t.x | (uint64_t)t.y << 32;
+        const uint32_t sh = t.x & 31u;
+        // this lane's four ids: elements e0 .. e0 + 3 of the list, e0 = 32 r + 4 p - sh
+        const int32_t e0 = (int32_t)(32u * r + 4u * p) - (int32_t)sh;
+        asm volatile("" : "=v"(v[j].x), "=v"(v[j].y), "=v"(v[j].z), "=v"(v[j].w));
+        const uint64_t at = (s0 & ~31ull) + 32u * r + 4u * p;
+        if (e0 + 3 >= 0 && e0 < (int32_t)t.z && at + 3 < cap + 32u) v[j] = *reinterpret_cast<const uint4 *>(tmp + at);
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint4 t = s_tab[wave][gsh | j];
+        const uint32_t sh = t.x & 31u;
+        const int32_t e0 = (int32_t)(32u * r + 4u * p) - (int32_t)sh;
+        const uint32_t x[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (e0 + k >= 0 && e0 + k < (int32_t)t.z) buf[t.w + (uint32_t)(e0 + k)] = x[k];
+      }
+    }
+    wave_sync_lds();
+    const uint32_t nthis = __shfl(loff + len, (int)next - 1, kWave) - base;
+    const uint64_t out0 = wb + base;
+    const uint32_t lim = cap > out0 ? (cap - out0 < nthis ? (uint32_t)(cap - out0) : nthis) : 0u;
+    {
+      typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4)));
+      uint32_t *const out = hits + out0;
+      const uint32_t n4 = lim & ~3u;
+      for (uint32_t e = lane * 4u; e < n4; e += kWave * 4u)
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4_a16 *>(buf + e), reinterpret_cast<u32x4_a4 *>(out + e));
+      if (n4 + lane < lim) stream_store(out + n4 + lane, buf[n4 + lane]);
+    }
+    wave_sync_lds();
+    first = next;
+  }
+}
+
 int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                          const uint32_t *d_perm, size_t n, uint32_t *d_counts, uint64_t *d_src_by_id,
                          uint64_t *d_offsets_scratch, uint32_t *d_tmp_hits, uint64_t cap, uint64_t *ws, bool self_clean,
@@ -1872,8 +1960,16 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
 int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
                          uint64_t cap, hipStream_t s) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_permute_lists, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s, d_offsets,
-                     d_src, d_tmp, d_hits, n, cap);
+  static const bool by_elements = [] {  // (BIVX_PERMUTE=elements: the first form, for comparison)
+    const char *e = std::getenv("BIVX_PERMUTE");
+    return e && e[0] == 'e';
+  }();
+  if (by_elements)
+    hipLaunchKernelGGL(k_permute_lists, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s, d_offsets,
+                       d_src, d_tmp, d_hits, n, cap);
+  else
+    hipLaunchKernelGGL(k_permute_lines, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s, d_offsets,
+                       d_src, d_tmp, d_hits, n, cap);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
