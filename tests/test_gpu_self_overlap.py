@@ -49,7 +49,7 @@ def _data(seed, n, nchrom=3, span=40_000_000, lmax=1000, inverted=0.0, long_ever
     return chrom, low, high
 
 
-@pytest.mark.parametrize("case", ["packed", "inverted entries", "dense"])
+@pytest.mark.parametrize("case", ["packed", "inverted entries", "dense", "lists of thousands"])
 def test_self_overlaps_equals_the_general_call(case, oracle):
     import torch
     from binary_amd import IntervalIndex
@@ -57,12 +57,16 @@ def test_self_overlaps_equals_the_general_call(case, oracle):
         chrom, low, high = _data(1, 400_000)
     elif case == "inverted entries":          # no packed records: every slice goes through the general enumeration
         chrom, low, high = _data(2, 200_000, inverted=0.05)
-    else:                                      # ~40 ids per query: windows of more than 32 slots
+    elif case == "dense":                      # ~40 ids per query: windows of more than 32 slots
         chrom, low, high = _data(3, 300_000, span=4_000_000)
+    else:                                      # ~1 600 ids per query, no crowded cell: lists longer than k_permute_lines
+        chrom, low, high = _data(4, 80_000, span=5_000_000, nchrom=2)                  # puts together in LDS
+        high = (low + np.random.default_rng(4).integers(70_000, 100_000, low.size)).astype(np.uint32)  # (one length class)
     n = low.size
     with IntervalIndex(0) as idx:
         idx.insert_node(low, high, chrom)
         idx.build()
+        assert idx.stats()["n_segments"] == len(np.unique(chrom))    # one length class: the fast path's territory
         for sort_by_id in (False, True):
             g_off, g_hits, H = _general(idx, torch, low, high, chrom, sort_by_id)
             s_off, s_hits = _self(idx, torch, n, H, sort_by_id)
