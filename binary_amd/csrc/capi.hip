@@ -1602,7 +1602,7 @@ int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *q
   bivx_filter dflt;
   BIVX_TRY(upload_filter(tmp, idx, filter, q, s, dflt));
   BIVX_TRY(bivx_fill_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, d_hits, s));
-  if (sort_by_id) BIVX_TRY(bivx_sort_hits_dev(idx, d_off, d_hits, q, s));
+  if (sort_by_id) BIVX_TRY(launch_sort_hits(d_off, d_hits, q, ~0ull, s, nullptr, 0, total ? total : 1));
   if (total) BIVX_HIP(hipMemcpyAsync(hit_ids_out, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
   return report_device_errors(idx, "bivx_fill");
@@ -1660,7 +1660,7 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
   uint32_t *d_hits = nullptr;
   int rc = tmp.alloc(&d_hits, (size_t)total);
   if (rc == 0) rc = bivx_fill_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, d_hits, s);
-  if (rc == 0 && sort_by_id) rc = bivx_sort_hits_dev(idx, d_off, d_hits, q, s);
+  if (rc == 0 && sort_by_id) rc = launch_sort_hits(d_off, d_hits, q, ~0ull, s, nullptr, 0, total ? total : 1);
   if (rc == 0 && hipMemcpyAsync(h, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost, s) != hipSuccess) rc = BIVX_E_HIP;
   if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = BIVX_E_HIP;
   if (rc != 0) {

@@ -166,9 +166,11 @@ int launch_fill(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_
                 size_t q, const uint64_t *d_offsets, uint32_t *d_hits, hipStream_t s);
 int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                size_t q, uint32_t *d_first, hipStream_t s);
-// d_cond != nullptr: the pass runs only if *d_cond == seq (the single-pass kernel asks for it that way)
+// d_cond != nullptr: the pass runs only if *d_cond == seq (the single-pass kernel asks for it that way).
+// total_hint: the number of ids if the caller knows it (0: `cap` is taken as an upper bound; the kernel's LDS stage, and
+// with it how many wavefronts a CU holds, is sized by the average list)
 int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, uint64_t cap, hipStream_t s,
-                     const uint32_t *d_cond = nullptr, uint32_t seq = 0);
+                     const uint32_t *d_cond = nullptr, uint32_t seq = 0, uint64_t total_hint = 0);
 // single pass: offsets[q+1] and hits (slots below cap only) in one kernel; ws: fused_workspace_bytes(q)
 size_t fused_workspace_bytes(size_t q);
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,

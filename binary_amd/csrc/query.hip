@@ -44,10 +44,14 @@ __global__ __launch_bounds__(kQThreads) void k_query(IndexView v, const uint32_t
   if (valid && M != Mode::Fill) out[q] = r;
 }
 
+// LDSN: words of LDS per wavefront. The usual path needs the wavefront's 64 lists to fit it; the stage was 16 KB per
+// wavefront whatever the lists — 8 wavefronts per CU, and the pass over config 5's 861 M ids took 7.8 ms, 0.9 TB/s. The host
+// now picks the smallest of four sizes that holds 1.3 x the average 64 lists (it knows the total, or an upper bound).
+template <uint32_t LDSN>
 __global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restrict__ offsets,
                                                          uint32_t *__restrict__ hits, size_t nq, uint64_t cap,
                                                          const uint32_t *__restrict__ cond, uint32_t seq) {
-  __shared__ uint32_t lds[kQWaves][kSortLds];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[kQWaves][LDSN];
   // conditional form: the single-pass kernel ordered the ids itself unless one of its wavefronts said otherwise
   if (cond && __hip_atomic_load(cond, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) return;
   const size_t q = (size_t)blockIdx.x * kQThreads + threadIdx.x;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(kQThreads) void k_sort_hits(const uint64_t *__restr
   }
   o0 = o0 < cap ? o0 : cap;  // a CSR that did not fit its buffer: nothing beyond the buffer is touched
   o1 = o1 < cap ? o1 : cap;
-  wave_sort_lists<kSortLds, kRankBlock, true>(lds[threadIdx.x >> 6], o0, o1, hits, threadIdx.x & (kWave - 1));
+  wave_sort_lists<LDSN, kRankBlock, true>(lds[threadIdx.x >> 6], o0, o1, hits, threadIdx.x & (kWave - 1));
 }
 
 // One wavefront answers up to 64 queries completely — counts, their prefix sum, offsets, ids in index order — for the
@@ -137,9 +141,19 @@ int launch_any(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_q
 }
 
 int launch_sort_hits(const uint64_t *d_offsets, uint32_t *d_hits, size_t q, uint64_t cap, hipStream_t s,
-                     const uint32_t *d_cond, uint32_t seq) {
+                     const uint32_t *d_cond, uint32_t seq, uint64_t total_hint) {
   if (q == 0) return 0;
-  hipLaunchKernelGGL(k_sort_hits, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q, cap, d_cond, seq);
+  // ids per 64 lists, by the total if the caller knows it, else by the buffer's capacity (an upper bound; ~0: unknown)
+  const uint64_t known = total_hint ? total_hint : cap;
+  const double per_wave = known == ~0ull ? 1e30 : 64.0 * (double)known / (double)q;
+  if (per_wave * 1.3 <= 512.0)
+    hipLaunchKernelGGL(k_sort_hits<512>, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q, cap, d_cond, seq);
+  else if (per_wave * 1.3 <= 1024.0)
+    hipLaunchKernelGGL(k_sort_hits<1024>, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q, cap, d_cond, seq);
+  else if (per_wave * 1.3 <= 2048.0)
+    hipLaunchKernelGGL(k_sort_hits<2048>, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q, cap, d_cond, seq);
+  else
+    hipLaunchKernelGGL(k_sort_hits<kSortLds>, dim3(tiles_for(q)), dim3(kQThreads), 0, s, d_offsets, d_hits, q, cap, d_cond, seq);
   BIVX_HIP(hipGetLastError());
   return 0;
 }

@@ -675,22 +675,149 @@ __device__ __forceinline__ void rank_sort_list(const uint32_t *in, uint32_t *out
   }
 }
 
+// One lane's list of up to N ids (N = 8, 16, 32) ordered by a sorting network on registers: in[off .. off + n) ->
+// outb[off .. off + n) ascending, `outb` may be `in` (missing ids are +inf and stay behind the list's end; ids are
+// distinct). 19 comparators for eight (two instructions each), 70 for sixteen (eight up, eight down, a bitonic merge), 220
+// for thirty-two — against
+// n * ceil(n / 8) * 16 instructions of the rank sort above, which every lane of a wavefront pays for the LONGEST list among
+// the 64: 2 930 vector instructions per wavefront at config 5 (lists of 8-35 ids), 78 % of the ordering pass's time.
+#define BIVX_NET_CE(i, j)                  \
+  {                                        \
+    const uint32_t lo_ = min(x[i], x[j]);  \
+    x[j] = max(x[i], x[j]);                \
+    x[i] = lo_;                            \
+  }
+#define BIVX_NET_SORT8(a0, a1, a2, a3, a4, a5, a6, a7) /* ascending in the order the indexes are given */                  \
+  BIVX_NET_CE(a0, a1) BIVX_NET_CE(a2, a3) BIVX_NET_CE(a4, a5) BIVX_NET_CE(a6, a7)                                       \
+  BIVX_NET_CE(a0, a2) BIVX_NET_CE(a1, a3) BIVX_NET_CE(a4, a6) BIVX_NET_CE(a5, a7)                                       \
+  BIVX_NET_CE(a1, a2) BIVX_NET_CE(a5, a6) BIVX_NET_CE(a0, a4) BIVX_NET_CE(a3, a7)                                       \
+  BIVX_NET_CE(a1, a5) BIVX_NET_CE(a2, a6) BIVX_NET_CE(a1, a4) BIVX_NET_CE(a3, a6) BIVX_NET_CE(a2, a4) BIVX_NET_CE(a3, a5) \
+  BIVX_NET_CE(a3, a4)
+template <uint32_t N>
+__device__ __forceinline__ void net_sort_list(const uint32_t *in, uint32_t *outb, uint32_t off, uint32_t n) {
+  static_assert(N == 8 || N == 16 || N == 32, "network sizes");
+  uint32_t x[N];
+#pragma unroll
+  for (uint32_t k = 0; k < N; ++k) x[k] = k < n ? in[off + k] : 0xFFFFFFFFu;
+  BIVX_NET_SORT8(0, 1, 2, 3, 4, 5, 6, 7)
+  if (N >= 16) {
+    BIVX_NET_SORT8(15, 14, 13, 12, 11, 10, 9, 8)
+#pragma unroll
+    for (uint32_t d = 8; d > 0; d >>= 1)
+#pragma unroll
+      for (uint32_t i = 0; i < 16u; ++i)
+        if ((i & d) == 0) BIVX_NET_CE(i, i + d)
+  }
+  if (N >= 32) {
+    // the second sixteen DESCENDING (eight up, eight down, merged with the larger of a pair at the lower index) ...
+    BIVX_NET_SORT8(16, 17, 18, 19, 20, 21, 22, 23)
+    BIVX_NET_SORT8(31, 30, 29, 28, 27, 26, 25, 24)
+#pragma unroll
+    for (uint32_t d = 8; d > 0; d >>= 1)
+#pragma unroll
+      for (uint32_t i = 16; i < 32u; ++i)
+        if (((i - 16u) & d) == 0) BIVX_NET_CE(i + d, i)
+    // ... and the bitonic merge of the thirty-two
+#pragma unroll
+    for (uint32_t d = 16; d > 0; d >>= 1)
+#pragma unroll
+      for (uint32_t i = 0; i < 32u; ++i)
+        if ((i & d) == 0) BIVX_NET_CE(i, i + d)
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < N; ++k)
+    if (k < n) outb[off + k] = x[k];
+}
+// ... and up to 64 ids with 32 registers, in place: the first thirty-two ordered and put back, the rest ordered in
+// registers, one comparator step between the two halves (the smaller of a pair stays in LDS, the larger in its register:
+// LDS then holds the smallest thirty-two, the registers the rest, both bitonic), and a bitonic merge of each half.
+__device__ __forceinline__ void net_sort_list64(uint32_t *in, uint32_t off, uint32_t n) {
+  uint32_t x[32];
+  auto merge32 = [&] {
+#pragma unroll
+    for (uint32_t d = 16; d > 0; d >>= 1)
+#pragma unroll
+      for (uint32_t i = 0; i < 32u; ++i)
+        if ((i & d) == 0) BIVX_NET_CE(i, i + d)
+  };
+  net_sort_list<32>(in, in, off, n < 32u ? n : 32u);
+  if (!__any(n > 32u)) return;
+  const uint32_t nb = n > 32u ? n - 32u : 0u;  // ids of the second half
+#pragma unroll
+  for (uint32_t k = 0; k < 32u; ++k) x[k] = k < nb ? in[off + 32u + k] : 0xFFFFFFFFu;
+  BIVX_NET_SORT8(0, 1, 2, 3, 4, 5, 6, 7)
+  BIVX_NET_SORT8(15, 14, 13, 12, 11, 10, 9, 8)
+#pragma unroll
+  for (uint32_t d = 8; d > 0; d >>= 1)
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; ++i)
+      if ((i & d) == 0) BIVX_NET_CE(i, i + d)
+  BIVX_NET_SORT8(16, 17, 18, 19, 20, 21, 22, 23)
+  BIVX_NET_SORT8(31, 30, 29, 28, 27, 26, 25, 24)
+#pragma unroll
+  for (uint32_t d = 8; d > 0; d >>= 1)
+#pragma unroll
+    for (uint32_t i = 16; i < 32u; ++i)
+      if (((i - 16u) & d) == 0) BIVX_NET_CE(i + d, i)
+  merge32();  // x ascending
+  // the step between the halves: the first half's i-th against the second half's (31 - i)-th
+  const uint32_t na = n < 32u ? n : 32u;
+#pragma unroll
+  for (uint32_t i = 0; i < 32u; ++i) {
+    const uint32_t a = i < na ? in[off + i] : 0xFFFFFFFFu;
+    const uint32_t lo = min(a, x[31u - i]);
+    x[31u - i] = max(a, x[31u - i]);
+    if (i < na) in[off + i] = lo;
+  }
+  merge32();
+#pragma unroll
+  for (uint32_t k = 0; k < 32u; ++k)
+    if (k < nb) in[off + 32u + k] = x[k];
+#pragma unroll
+  for (uint32_t k = 0; k < 32u; ++k) x[k] = k < na ? in[off + k] : 0xFFFFFFFFu;
+  merge32();
+#pragma unroll
+  for (uint32_t k = 0; k < 32u; ++k)
+    if (k < na) in[off + k] = x[k];
+}
+#undef BIVX_NET_SORT8
+#undef BIVX_NET_CE
+
 // Sorts the 64 hit lists of one wavefront, hits[o0 .. o1) per lane (adjacent in memory, lane order), ascending,
 // in place. `lds` is the wavefront's own stage of LDSN words. All 64 lanes must call it.
 // SKIP_SORTED: look first whether every list is ascending already, and leave then.
 template <uint32_t LDSN, uint32_t RB, bool SKIP_SORTED = false>
 __device__ __forceinline__ void wave_sort_lists(uint32_t *lds, uint64_t o0, uint64_t o1, uint32_t *hits, int lane) {
   const uint64_t cnt = o1 - o0;
-  // Fast path, the usual case: every list of the wavefront is short and the 64 lists fit half the stage. The
-  // region is loaded with coalesced reads, every lane rank-sorts its own list out of LDS into the other half,
-  // which is streamed back coalesced.
+  // Fast path, the usual case: every list of the wavefront has at most 64 ids and the 64 lists fit the stage. The
+  // region is loaded with coalesced reads, every lane orders its own list where it lies (a sorting network on
+  // registers), and the region is streamed back coalesced.
   const uint64_t wb = __shfl((unsigned long long)o0, 0, kWave);
   const uint64_t we = __shfl((unsigned long long)o1, kWave - 1, kWave);
-  if (__all(cnt <= kRankMax) && we - wb <= LDSN / 2) {
+  if (__all(cnt <= 64u) && we - wb <= LDSN) {
     const uint32_t wtotal = (uint32_t)(we - wb);
-    uint32_t *in = lds, *outb = lds + LDSN / 2;
+    uint32_t *in = lds, *outb = lds;  // (every lane orders its own list where it lies)
     if (__any(cnt > 1)) {
-      for (uint32_t i = lane; i < wtotal; i += kWave) in[i] = hits[wb + i];
+      {  // the region in, sixteen bytes per lane and instruction (the region begins at any 4-byte boundary: gfx950's
+         // unaligned access mode), the loads of a trip leaving together
+        typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));
+        const uint32_t n4 = wtotal & ~3u;
+        const uint32_t *src = hits + wb;
+        for (uint32_t i0 = (uint32_t)lane * 4u; i0 < n4; i0 += kWave * 16u) {
+          u32x4_a4 v[4];
+#pragma unroll
+          for (uint32_t u = 0; u < 4; ++u)
+            if (i0 + u * kWave * 4u < n4) v[u] = *reinterpret_cast<const u32x4_a4 *>(src + i0 + u * kWave * 4u);
+#pragma unroll
+          for (uint32_t u = 0; u < 4; ++u)
+            if (i0 + u * kWave * 4u < n4) {
+              u32x4_lds w;
+              w.x = v[u].x; w.y = v[u].y; w.z = v[u].z; w.w = v[u].w;
+              *reinterpret_cast<u32x4_lds *>(in + i0 + u * kWave * 4u) = w;
+            }
+        }
+        if (n4 + (uint32_t)lane < wtotal) in[n4 + lane] = src[n4 + lane];
+      }
       wave_sync_mem();
       // Already ascending (position-sorted input has ids in index order inside a length class, so a sorted VCF
       // mostly arrives this way): nothing to rank and nothing to write back.
@@ -700,9 +827,32 @@ __device__ __forceinline__ void wave_sort_lists(uint32_t *lds, uint64_t o0, uint
           ascending = ascending && in[(uint32_t)(o0 - wb) + i - 1] < in[(uint32_t)(o0 - wb) + i];
         if (__all(ascending)) return;
       }
-      rank_sort_list<RB>(in, outb, (uint32_t)(o0 - wb), (uint32_t)cnt);
+      {
+        // a sorting network on registers, sized by the longest list of the wavefront
+        const uint32_t off = (uint32_t)(o0 - wb), n = (uint32_t)cnt;
+        const uint32_t longest = wave_max(n);
+        if (longest <= 8u)
+          net_sort_list<8>(in, outb, off, n);
+        else if (longest <= 16u)
+          net_sort_list<16>(in, outb, off, n);
+        else if (longest <= 32u)
+          net_sort_list<32>(in, outb, off, n);
+        else
+          net_sort_list64(in, off, n);
+      }
       wave_sync_mem();
-      for (uint32_t i = lane; i < wtotal; i += kWave) hits[wb + i] = outb[i];
+      {  // ... and out the same way
+        typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));
+        const uint32_t n4 = wtotal & ~3u;
+        uint32_t *dst = hits + wb;
+        for (uint32_t i0 = (uint32_t)lane * 4u; i0 < n4; i0 += kWave * 4u) {
+          const u32x4_lds w = *reinterpret_cast<const u32x4_lds *>(outb + i0);
+          u32x4_a4 v;
+          v.x = w.x; v.y = w.y; v.z = w.z; v.w = w.w;
+          *reinterpret_cast<u32x4_a4 *>(dst + i0) = v;
+        }
+        if (n4 + (uint32_t)lane < wtotal) dst[n4 + lane] = outb[n4 + lane];
+      }
       wave_sync_mem();
     }
     return;

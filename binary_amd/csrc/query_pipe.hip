@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
   __shared__ SegDesc s_seg[kLdsSegs];
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ uint32_t s_last;
-  __shared__ uint32_t s_sort[S ? kQWaves : 1][S ? kSortLds / 2 : 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_sort[S ? kQWaves : 1][S ? kSortLds / 2 : 4];
   const uint32_t *todo = reinterpret_cast<const uint32_t *>(a.ws + kWsList);
   const uint32_t n =
       __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.ws + kWsTodo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
