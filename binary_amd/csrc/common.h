@@ -200,7 +200,7 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
                          uint64_t *d_offsets_scratch, uint32_t *d_tmp_hits, uint64_t cap, uint64_t *ws, bool self_clean,
                          hipStream_t s);
 int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
-                         uint64_t cap, hipStream_t s);
+                         uint64_t cap, bool sort_ids, bool *sorted, hipStream_t s);
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
                       int flags, uint32_t sort_seq, uint32_t *d_counts, uint64_t *d_total, hipStream_t s);

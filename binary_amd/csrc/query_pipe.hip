@@ -1850,6 +1850,8 @@ __global__ __launch_bounds__(kQThreads) void k_permute_lists(const uint64_t *__r
 constexpr uint32_t kPermBuf = BIVX_PERM_BUF;      // ids a wavefront puts together at a time (6 KB: 1024 / 1536 / 2048 / 3072 / 4096 -> 5.11 / 4.48 / 4.59 / 4.84 / 5.65 ms at config 5)
 constexpr uint32_t kPermListMax = 1024;  // a wavefront with a longer list takes the element-wise way
 
+// S: every list leaves in ascending order (ordered by its lane while the piece sits in LDS: no second pass over the ids)
+template <bool S>
 __global__ __launch_bounds__(kQThreads) void k_permute_lines(const uint64_t *__restrict__ offsets,
                                                              const uint64_t *__restrict__ src, const uint32_t *__restrict__ tmp,
                                                              uint32_t *__restrict__ hits, size_t n, uint64_t cap) {
@@ -1866,6 +1868,11 @@ __global__ __launch_bounds__(kQThreads) void k_permute_lines(const uint64_t *__r
     if (i < n)
       for (uint64_t k = 0; k < o1 - o0; ++k)
         if (o0 + k < cap && sp + k < cap) hits[o0 + k] = tmp[sp + k];
+    if (S) {
+      wave_sync_mem();
+      const uint64_t c0 = o0 < cap ? o0 : cap, c1 = o1 < cap ? o1 : cap;
+      wave_sort_lists<kPermBuf, kRankBlock, false>(s_buf[wave], c0, c1, hits, (int)lane);
+    }
     return;
   }
   const uint32_t len = (uint32_t)(o1 - o0), loff = (uint32_t)(o0 - wb);
@@ -1909,6 +1916,29 @@ __global__ __launch_bounds__(kQThreads) void k_permute_lines(const uint64_t *__r
       }
     }
     wave_sync_lds();
+    if (S) {  // every lane of the run orders its own list where it lies (lists of up to kPermListMax ids)
+      const uint32_t nl = mine ? len : 0u, off = loff - base, longest = wave_max(nl);
+      if (longest <= 8u)
+        net_sort_list<8>(buf, buf, off, nl);
+      else if (longest <= 16u)
+        net_sort_list<16>(buf, buf, off, nl);
+      else if (longest <= 32u)
+        net_sort_list<32>(buf, buf, off, nl);
+      else if (longest <= 64u)
+        net_sort_list64(buf, off, nl);
+      else {
+        // (rare: a list beyond 64 ids — the whole wavefront orders such a list, one after the other)
+        net_sort_list64(buf, off, nl <= 64u ? nl : 0u);
+        uint64_t todo = __ballot(nl > 64u);
+        while (todo) {
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          wave_sync_mem();
+          wave_bitonic_sort<uint32_t>(buf + __shfl(off, src, kWave), __shfl(nl, src, kWave), (int)lane);
+        }
+      }
+      wave_sync_lds();
+    }
     const uint32_t nthis = __shfl(loff + len, (int)next - 1, kWave) - base;
     const uint64_t out0 = wb + base;
     const uint32_t lim = cap > out0 ? (cap - out0 < nthis ? (uint32_t)(cap - out0) : nthis) : 0u;
@@ -1957,8 +1987,10 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
   return 0;
 }
 
+// *sorted: the lists left in ascending order (sort_ids asked for it and the line-wise kernel ran), else the caller orders them
 int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
-                         uint64_t cap, hipStream_t s) {
+                         uint64_t cap, bool sort_ids, bool *sorted, hipStream_t s) {
+  *sorted = false;
   if (n == 0) return 0;
   static const bool by_elements = [] {  // (BIVX_PERMUTE=elements: the first form, for comparison)
     const char *e = std::getenv("BIVX_PERMUTE");
@@ -1967,9 +1999,14 @@ int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const
   if (by_elements)
     hipLaunchKernelGGL(k_permute_lists, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s, d_offsets,
                        d_src, d_tmp, d_hits, n, cap);
-  else
-    hipLaunchKernelGGL(k_permute_lines, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s, d_offsets,
-                       d_src, d_tmp, d_hits, n, cap);
+  else if (sort_ids) {
+    hipLaunchKernelGGL(k_permute_lines<true>, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s,
+                       d_offsets, d_src, d_tmp, d_hits, n, cap);
+    *sorted = true;
+  } else {
+    hipLaunchKernelGGL(k_permute_lines<false>, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s,
+                       d_offsets, d_src, d_tmp, d_hits, n, cap);
+  }
   BIVX_HIP(hipGetLastError());
   return 0;
 }
