@@ -49,7 +49,7 @@ def _data(seed, n, nchrom=3, span=40_000_000, lmax=1000, inverted=0.0, long_ever
     return chrom, low, high
 
 
-@pytest.mark.parametrize("case", ["packed", "inverted entries", "dense", "lists of thousands"])
+@pytest.mark.parametrize("case", ["packed", "inverted entries", "dense", "lists of a hundred", "lists of thousands"])
 def test_self_overlaps_equals_the_general_call(case, oracle):
     import torch
     from binary_amd import IntervalIndex
@@ -59,6 +59,9 @@ def test_self_overlaps_equals_the_general_call(case, oracle):
         chrom, low, high = _data(2, 200_000, inverted=0.05)
     elif case == "dense":                      # ~40 ids per query: windows of more than 32 slots
         chrom, low, high = _data(3, 300_000, span=4_000_000)
+    elif case == "lists of a hundred":         # 60-180 ids per query: beyond the sorting networks, runs of a few lists
+        chrom, low, high = _data(5, 70_000, span=600_000, nchrom=1)
+        high = (low + np.random.default_rng(5).integers(600, 1000, low.size)).astype(np.uint32)    # (one length class)
     else:                                      # ~1 600 ids per query, no crowded cell: lists longer than k_permute_lines
         chrom, low, high = _data(4, 80_000, span=5_000_000, nchrom=2)                  # puts together in LDS
         high = (low + np.random.default_rng(4).integers(70_000, 100_000, low.size)).astype(np.uint32)  # (one length class)
