@@ -51,10 +51,16 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_reduce(const uint32_t *__
   __shared__ OutT lds[kScanThreads / kWave];
   const size_t base = (size_t)blockIdx.x * kScanTile;
   OutT acc = 0;
+  if (base + kScanTile <= n) {  // a full tile: two 16-byte loads per thread (order is irrelevant for a sum)
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
+    const uint4 a = p[threadIdx.x], b = p[kScanThreads + threadIdx.x];
+    acc = (OutT)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+  } else {
 #pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    size_t i = base + (size_t)k * kScanThreads + threadIdx.x;  // coalesced, order is irrelevant for a sum
-    if (i < n) acc += in[i];
+    for (int k = 0; k < kScanItems; ++k) {
+      size_t i = base + (size_t)k * kScanThreads + threadIdx.x;
+      if (i < n) acc += in[i];
+    }
   }
   OutT total;
   (void)block_exclusive_scan<OutT>(acc, lds, total);
