@@ -499,11 +499,14 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
     while (hm) {
       const int src = __ffsll((long long)hm) - 1;
       hm &= hm - 1;
-      uint32_t ca = __shfl(w.a, src, kWave), cb = __shfl(w.b, src, kWave);
-      const uint32_t cl = __shfl(lo, src, kWave), ch = __shfl(hi, src, kWave);
-      const uint32_t cx = F ? __shfl(qy.aux, src, kWave) : 0u;
+      // (`src` is the same in every lane: a lane's register is read straight into a scalar — v_readlane — where __shfl
+      // goes through the LDS crossbar and is waited for, six times per window)
+      auto of_src = [&](uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, src); };
+      uint32_t ca = of_src(w.a), cb = of_src(w.b);
+      const uint32_t cl = of_src(lo), ch = of_src(hi);
+      const uint32_t cx = F ? of_src(qy.aux) : 0u;
       if (cb - ca > kTrim) {  // long window: trim it to the slots with low in [q.low - maxlen, q.high]
-        ca = wave_lower_bound_low(v.se, ca, cb, __shfl(xlow, src, kWave), lane);
+        ca = wave_lower_bound_low(v.se, ca, cb, of_src(xlow), lane);
         if (ch != 0xFFFFFFFFu) cb = wave_lower_bound_low(v.se, ca, cb, ch + 1u, lane);
       }
       auto is_hit = [&](uint32_t j) {
@@ -524,7 +527,7 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
             if (j < cb && e[r].x <= ch && e[r].y >= cl && (!F || filter_accept(v, cl, ch, cx, e[r].x, e[r].y, v.id[j]))) ++c;
           }
         }
-        c = wave_sum(c);
+        c = wave_sum(c);  // (a row's hits counted on its ballot instead: slower — 0.86 against 0.77 ms on tools/clustered_bench.py)
         if (lane == src) acc += c;
       } else if (M == Mode::Any) {
         uint32_t m = BIVX_NO_HIT;
@@ -536,7 +539,7 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
         // ballot compaction keeps ascending slot order: the output does not depend on which path ran
         // kHeavyRows rows of 64 slots are loaded together, ids included (a row's ids are one coalesced load; fetching
         // them only for hits would put a dependent load between the ballot and the store of every row).
-        const uint64_t pos0 = __shfl((unsigned long long)(dst_pos + acc), src, kWave);
+        const uint64_t pos0 = (uint64_t)of_src((uint32_t)(dst_pos + acc)) | (uint64_t)of_src((uint32_t)((dst_pos + acc) >> 32)) << 32;
         uint32_t written = 0;
         for (uint32_t j0 = ca + lane; j0 < cb + lane; j0 += kHeavyRows * kWave) {  // wavefront-uniform trip count
           uint2 e[kHeavyRows];
