@@ -181,6 +181,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
 // query_pipe.hip: the pipelined single-pass kernel for the common case; launch_query_fused dispatches to it
 bool pipe_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bool unordered);
 size_t pipe_queries_per_launch();
+size_t pipe_ms_queries_per_launch();  // (k_query_pipe_ms has tiles of its own size)
 bool pipe_dense_eligible(const IndexView &v, size_t q, uint64_t cap, bool sort_ids, bool unordered);
 int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                             size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,

@@ -468,7 +468,10 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
   // ... and so has everything else that is large (several segments per chromosome, fused filters, many ids per query in
   // any order): a position-sorted batch is left to the dense kernel (which leaves the word for this one to see)
   const bool use_ms = !use_pipe && pipe_ms_eligible(v, q, cap, unordered);
-  const size_t per_launch = use_pipe || try_dense || use_ms ? pipe_tile * max_tiles_pipe : (size_t)max_tiles * kFTile;
+  const size_t ms_tile = pipe_ms_queries_per_launch() / kFMaxTiles;
+  // (a launch pair k_query_pipe_dense | k_query_pipe_ms is cut at the smaller of the two kernels' limits)
+  const size_t per_launch = use_ms ? ms_tile * max_tiles_pipe
+                                   : use_pipe || try_dense ? pipe_tile * max_tiles_pipe : (size_t)max_tiles * kFTile;
   // caller's workspace: zeroed in front of every launch (ordered output), or once per call (unordered output:
   // the running total lives in it across the call's launches)
   if (!self_clean && unordered && !use_pipe) BIVX_HIP(hipMemsetAsync(d_ws, 0, (size_t)kWsStatus * sizeof(uint64_t), s));
@@ -476,7 +479,7 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     const size_t q1 = q0 + per_launch < q ? q0 + per_launch : q;
     const size_t tile_q = use_pipe ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
     const unsigned tiles = (unsigned)((q1 - q0 + tile_q - 1) / tile_q);
-    const size_t tile_small = use_pipe || try_dense || use_ms ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
+    const size_t tile_small = use_ms ? ms_tile : use_pipe || try_dense ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
     if (!self_clean && (!unordered || use_pipe))
       BIVX_HIP(hipMemsetAsync(d_ws, 0, ((q1 - q0 + tile_small - 1) / tile_small + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
     const dim3 grid(tiles), block(kFThreads);

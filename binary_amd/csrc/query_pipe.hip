@@ -34,7 +34,10 @@
 namespace bivx {
 namespace {
 
-constexpr int kPThreads = 1024;
+#ifndef BIVX_PIPE_THREADS
+#define BIVX_PIPE_THREADS 1024  // (experiments: 512 = seven workers and the service wavefront)
+#endif
+constexpr int kPThreads = BIVX_PIPE_THREADS;
 constexpr int kPWaves = kPThreads / kWave;
 constexpr int kWorkers = kPWaves - 1;          // wavefront kWorkers is the service wavefront
 constexpr uint32_t kPTile = kWorkers * kWave;  // 960 queries
@@ -85,6 +88,7 @@ struct PipeArgs {
   uint64_t *src_by_id;
   uint32_t *dst_counts;
   uint32_t rec_delta;  // k_query_pipe_ms: byte distance from se[] to rec[] (one block, below 4 GB)
+  uint32_t tile_q;     // queries per tile of the kernel that listed slices for k_fill_slices (960; k_query_pipe_ms: 448)
 };
 constexpr int kFlagSorted = 4;  // k_query_pipe_dense: the batch is known to be position-sorted (no order probe was launched)
 
@@ -323,6 +327,7 @@ __device__ __forceinline__ uint32_t coop_mask32(const uint2 *rec, uint32_t *keep
 
 // The service wavefront of a pipelined workgroup (k_query_pipe and k_query_pipe_dense): tickets, published totals, the
 // sweeps over the earlier tiles, the workers' bases — everything that talks to other workgroups.
+template <int NW>  // worker wavefronts of the workgroup (the service wavefront is wavefront NW)
 __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, int lane) {
   // ================================ the service wavefront ================================================
   PrefixCtx pc;
@@ -354,13 +359,13 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
     if (drawing && drawn - swept < kRing) {
       bool want = drawn == 0;
 #ifdef BIVX_TICKET_EARLY   // experiment: a whole counting phase ahead (when every worker has begun the tile before)
-      if (!want) want = drawn == 1 || lds_load(&s_slot[(drawn - 2) % kRing].arrived) == (uint32_t)kWorkers;
+      if (!want) want = drawn == 1 || lds_load(&s_slot[(drawn - 2) % kRing].arrived) == (uint32_t)NW;
 #else
       if (!want) want = lds_load(&s_slot[(drawn - 1) % kRing].arrived) != 0;
 #endif
       TileSlot &sl = s_slot[drawn % kRing];
       // (the slot's last user was iteration drawn - kRing: swept, but every worker must also be through with it)
-      if (want && (drawn < kRing || lds_load(&sl.flushed) == (uint32_t)kWorkers)) {
+      if (want && (drawn < kRing || lds_load(&sl.flushed) == (uint32_t)NW)) {
         uint32_t tile = 0;
         if (lane == 0) {
           tile = atomicAdd(reinterpret_cast<unsigned int *>(A(ws) + kWsTicket), 1u);
@@ -383,16 +388,16 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
     // ---- publish ----
     if (published < real) {
       TileSlot &ps = s_slot[published % kRing];
-      if (lds_load(&ps.arrived) == (uint32_t)kWorkers) {
-        const uint64_t mine = lane < kWorkers ? ps.wsum[lane] : 0ull;
+      if (lds_load(&ps.arrived) == (uint32_t)NW) {
+        const uint64_t mine = lane < NW ? ps.wsum[lane] : 0ull;
         uint64_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 16; d <<= 1) {
           const uint64_t o = __shfl_up((unsigned long long)incl, d, kWave);
           if (lane >= d) incl += o;
         }
-        if (lane < kWorkers) ps.wbase[lane] = incl - mine;
-        const uint64_t total = __shfl((unsigned long long)incl, kWorkers - 1, kWave);
+        if (lane < NW) ps.wbase[lane] = incl - mine;
+        const uint64_t total = __shfl((unsigned long long)incl, NW - 1, kWave);
         if (lane == 0) {
           ps.base = total;  // parked here until the sweep replaces it with the tile's first position
           st_status(&pc.status[ps.tile], kStValid | total);
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
   const uint2 *const cs = s_cs;
 
   if (wave == kWorkers) {
-    pipe_service_wave(ka, s_slot, lane);
+    pipe_service_wave<kWorkers>(ka, s_slot, lane);
     return;
   }
 
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
   const SegDesc *const segs = s_seg;
   const uint2 *const cs = s_cs;
   if (wave == kWorkers) {
-    pipe_service_wave(ka, s_slot, lane);
+    pipe_service_wave<kWorkers>(ka, s_slot, lane);
     return;
   }
 
@@ -1158,10 +1163,20 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
 // A slice with a window beyond kMsLaneMax slots, or a list longer than a stage, is counted by the general enumeration
 // and listed for k_fill_slices, as in k_query_pipe.
 #ifndef BIVX_MS_WAVES
-#define BIVX_MS_WAVES 4  // wavefronts per SIMD the kernel is built for: 4 = one workgroup per CU, 128 registers, 160 KB of LDS
+#define BIVX_MS_WAVES 4  // wavefronts per SIMD the kernel is built for: 4 = 128 registers
 #endif
+// Workgroups of 512 threads — seven workers and the service wavefront, tiles of 448 queries — two per CU (80 KB of LDS
+// each): 1 024 threads as in k_query_pipe, one workgroup per CU, ran 0.142 / 0.539 ms on tools/skewed_bench.py 1e4 / 1e5
+// where this runs 0.136 / 0.493; 256 threads 0.159 / 0.505.
+constexpr int kMsThreads = 512;
+constexpr int kMsWorkers = kMsThreads / kWave - 1;
+constexpr uint32_t kMsTile = kMsWorkers * kWave;
 constexpr uint32_t kMsKeepN = 16;                                // ids a lane keeps while its slice is pending
+#ifdef BIVX_MS_NOKEEP
+constexpr uint32_t kMsKeepWords = 0;
+#else
 constexpr uint32_t kMsKeepWords = kMsKeepN * kWave;              // ... a wavefront's keep slots, one pending slice
+#endif
 constexpr uint32_t kMsBuf = 448;      // ids a wavefront lines up per round on their way out
 static_assert(kMsBuf >= 6 * kWave, "the walk's table of window words lives in the buffer");
 constexpr uint32_t kMsStage = 2 * kMsKeepWords + kMsBuf;         // a wavefront's LDS: two pending slices' keep slots + the buffer
@@ -1342,14 +1357,14 @@ __device__ __forceinline__ uint32_t group_scan(kargs_t ka, const SegDesc *segs, 
 }
 
 template <bool F>
-__global__ __launch_bounds__(kPThreads, BIVX_MS_WAVES) void k_query_pipe_ms(IndexView v_in, PipeArgs a_in) {
+__global__ __launch_bounds__(kMsThreads, BIVX_MS_WAVES) void k_query_pipe_ms(IndexView v_in, PipeArgs a_in) {
   (void)v_in;
   (void)a_in;
   kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ SegDesc s_seg[kLdsSegs];
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ TileSlot s_slot[kRing];
-  __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWorkers][kMsStage];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[kMsWorkers][kMsStage];
   {  // behind k_query_pipe_dense: that kernel did the launch's work if the order probe left this launch's number
     kargs_t p = fresh(ka);
     if (p->a.seq != 0 && __hip_atomic_load(reinterpret_cast<const uint32_t *>(p->a.ws + kWsOrder), __ATOMIC_RELAXED,
@@ -1363,9 +1378,9 @@ __global__ __launch_bounds__(kPThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Inde
     const uint4 *src = reinterpret_cast<const uint4 *>(p->v.seg);
     uint4 *dst = reinterpret_cast<uint4 *>(s_seg);
     const uint32_t nseg2 = p->v.nseg * 2, nchrom = p->v.nchrom;
-    for (uint32_t t = threadIdx.x; t < nseg2; t += kPThreads) dst[t] = src[t];
+    for (uint32_t t = threadIdx.x; t < nseg2; t += kMsThreads) dst[t] = src[t];
     const uint2 *rng = p->v.chrom_rng;
-    for (uint32_t t = threadIdx.x; t < nchrom; t += kPThreads) s_cs[t] = rng[t];
+    for (uint32_t t = threadIdx.x; t < nchrom; t += kMsThreads) s_cs[t] = rng[t];
     if (threadIdx.x < kRing) {
       s_slot[threadIdx.x].gen_ticket = 0;
       s_slot[threadIdx.x].gen_base = 0;
@@ -1376,14 +1391,14 @@ __global__ __launch_bounds__(kPThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Inde
   __syncthreads();
   const SegDesc *const segs = s_seg;
   const uint2 *const cs = s_cs;
-  if (wave == kWorkers) {
-    pipe_service_wave(ka, s_slot, lane);
+  if (wave == kMsWorkers) {
+    pipe_service_wave<kMsWorkers>(ka, s_slot, lane);
     return;
   }
 
   auto query_of = [&](uint32_t t) {
     kargs_t p = fresh(ka);
-    const size_t q = p->a.q_begin + (size_t)t * kPTile + threadIdx.x;
+    const size_t q = p->a.q_begin + (size_t)t * kMsTile + threadIdx.x;
     IndexView w;
     w.nchrom = p->v.nchrom;
     w.flt_qaux = p->v.flt_qaux;
@@ -1407,7 +1422,7 @@ __global__ __launch_bounds__(kPThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Inde
     const uint64_t wpos0 = os.base + os.wbase[wave];
     kargs_t p = fresh(ka);
     const size_t q_end = p->a.q_end;
-    const size_t q = p->a.q_begin + (size_t)pd.tile * kPTile + threadIdx.x;
+    const size_t q = p->a.q_begin + (size_t)pd.tile * kMsTile + threadIdx.x;
     const uint64_t cap = p->a.cap;
     if (q < q_end) {
       uint64_t *off = p->a.offsets;
@@ -1455,7 +1470,11 @@ __global__ __launch_bounds__(kPThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Inde
   lds_wait_eq(&s_slot[0].gen_ticket, 1u);
   uint32_t tile = __builtin_amdgcn_readfirstlane(s_slot[0].tile);
   Query qy = query_of(tile);
+#ifdef BIVX_MS_NOKEEP  // experiment: every slice is walked twice, no keep slots in use
+  bool keep_mode = false;
+#else
   bool keep_mode = true;
+#endif
 
   for (uint32_t it = 0;; ++it) {
     const bool live = tile < A(ntiles);
@@ -1504,7 +1523,9 @@ __global__ __launch_bounds__(kPThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Inde
     const bool general = too_long || huge;
     const bool fits = !general && !__any(cnt > kMsKeepN);
     const bool kept = fits && !no_ids;
+#ifndef BIVX_MS_NOKEEP
     if (!general) keep_mode = fits;
+#endif
     uint32_t wtotal = wave_last(incl);
     uint64_t wt64 = wtotal, lpos64 = incl - cnt;
     if (huge) {
@@ -1581,7 +1602,7 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
   for (uint32_t w = blockIdx.x * kQWaves + wave; w < n; w += gridDim.x * kQWaves) {
     const uint32_t e = todo[w];
-    const size_t q = a.q_begin + (size_t)(e >> 4) * kPTile + (size_t)(e & 15u) * kWave + lane;
+    const size_t q = a.q_begin + (size_t)(e >> 4) * a.tile_q + (size_t)(e & 15u) * kWave + lane;
     const bool valid = q < a.q_end;
     const Query qy = load_query<F>(v, cs, a.qchrom, a.qlow, a.qhigh, q, valid);
     const uint64_t pos = !valid ? 0 : a.perm ? a.src_by_id[a.perm[q]] : a.offsets[q];
@@ -1676,17 +1697,18 @@ bool pipe_ms_eligible(const IndexView &v, size_t q, uint64_t cap, bool unordered
 }
 
 size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }
+size_t pipe_ms_queries_per_launch() { return (size_t)kFMaxTiles * kMsTile; }
 
 int launch_query_pipe_ms(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                          size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
                          int flags, uint32_t skip_seq, hipStream_t s) {
-  const unsigned tiles = (unsigned)((q1 - q0 + kPTile - 1) / kPTile);
-  unsigned wgs = 256;
+  const unsigned tiles = (unsigned)((q1 - q0 + kMsTile - 1) / kMsTile);
+  unsigned wgs = 512;
   {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      wgs = (unsigned)cus * (BIVX_MS_WAVES <= 4 ? 1u : 2u);  // one workgroup per CU: 128 registers, the whole LDS
+      wgs = 2u * (unsigned)cus;  // two workgroups of 512 threads per CU: 128 registers, 79 KB of LDS each
     if (const char *e = std::getenv("BIVX_PIPE_WGS")) {
       const long w = std::atol(e);
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
@@ -1694,13 +1716,14 @@ int launch_query_pipe_ms(const IndexView &v, const uint32_t *d_qchrom, const uin
   }
   // (seq: launched behind k_query_pipe_dense, which did the launch's work if the order probe left this number)
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, skip_seq, nullptr, nullptr,
-             nullptr, nullptr, nullptr, (uint32_t)(reinterpret_cast<const char *>(v.rec) - reinterpret_cast<const char *>(v.se))};
+             nullptr, nullptr, nullptr, (uint32_t)(reinterpret_cast<const char *>(v.rec) - reinterpret_cast<const char *>(v.se)),
+             kMsTile};
   const dim3 grid(tiles < wgs ? tiles : wgs);
   if (v.flt_kind != BIVX_FILTER_NONE) {
-    hipLaunchKernelGGL(k_query_pipe_ms<true>, grid, dim3(kPThreads), 0, s, v, a);
+    hipLaunchKernelGGL(k_query_pipe_ms<true>, grid, dim3(kMsThreads), 0, s, v, a);
     if (cap != 0) hipLaunchKernelGGL((k_fill_slices<false, true>), dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
   } else {
-    hipLaunchKernelGGL(k_query_pipe_ms<false>, grid, dim3(kPThreads), 0, s, v, a);
+    hipLaunchKernelGGL(k_query_pipe_ms<false>, grid, dim3(kMsThreads), 0, s, v, a);
     if (cap != 0) hipLaunchKernelGGL((k_fill_slices<false, false>), dim3(kFillBlocks), dim3(kQThreads), 0, s, v, a);
   }
   BIVX_HIP(hipGetLastError());
@@ -1723,7 +1746,7 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
     }
   }
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, sort_seq, d_counts, d_total,
-             nullptr, nullptr, nullptr, 0u};
+             nullptr, nullptr, nullptr, 0u, kPTile};
   if (sort_seq)
     hipLaunchKernelGGL(k_query_pipe<true>, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   else
@@ -1755,7 +1778,7 @@ int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const 
     }
   }
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, q0, q1, d_offsets, d_hits, cap, ws, tiles, flags, seq, nullptr, nullptr,
-             nullptr, nullptr, nullptr, 0u};
+             nullptr, nullptr, nullptr, 0u, kPTile};
   hipLaunchKernelGGL(k_probe_order, dim3(1), dim3(256), 0, s, d_qchrom, d_qlow, q0, q1, ws, seq);
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   a.seq = 0;  // (k_fill_slices: index order)
@@ -1977,7 +2000,7 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
   }
   const unsigned tiles = (unsigned)((n + kPTile - 1) / kPTile);
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, 0, n, d_offsets_scratch, d_tmp_hits, cap, ws, tiles, flags, 1u,
-             nullptr, nullptr, d_perm, d_src_by_id, d_counts, 0u};
+             nullptr, nullptr, d_perm, d_src_by_id, d_counts, 0u, kPTile};
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   if (cap != 0) {
     a.seq = 0;  // (k_fill_slices: index order)
