@@ -18,7 +18,8 @@ low, high = synth.gen_intervals(1_000_000, L, 1000, 0)
 idx = IntervalIndex(0)
 idx.insert_node(to(low), to(high))
 idx.build()
-for q in (131072, 262144, 393216, 524288, 655360, 786432, 1000000, 1310720, 2097152):
+SIZES = [int(x) for x in sys.argv[1:]] or [131072, 262144, 393216, 524288, 655360, 786432, 1000000, 1310720, 2097152]
+for q in SIZES:
     qlo, qhi = synth.gen_point_queries(q, L, 0)
     ql, qh = to(qlo), to(qhi)
     off = torch.empty(q + 1, dtype=torch.int64, device=dev)
