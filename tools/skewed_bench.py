@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """SV-like length spectrum: 1 M intervals with log-uniform lengths 50 bp .. MAXLEN (argv[1], default 10 Mbp) on one
-chromosome, 1 M point queries. Prints the length classes the planner chose and the single-pass time."""
+chromosome, 1 M point queries (argv[2]: another number of queries). Prints the length classes the planner chose and the single-pass time."""
 import sys
 import numpy as np
 import torch
@@ -8,7 +8,8 @@ sys.path.insert(0, ".")
 from binary_amd import IntervalIndex
 rng = np.random.default_rng(5)
 L = 248_956_422
-n = q = 1_000_000
+n = 1_000_000
+q = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000
 low = rng.integers(0, L - 10_000_001, size=n).astype(np.uint32)
 MAXLEN = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 ln = np.exp(rng.uniform(np.log(50), np.log(MAXLEN), size=n)).astype(np.uint32)
