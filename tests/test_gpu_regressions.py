@@ -313,3 +313,46 @@ def test_destroyed_index_objects_are_reused_by_the_next_create(monkeypatch):
         _check_csr(o[0][0], o[0][1], exp, True)
         if t[3] is not None:
             _check_csr(o[1][0], o[1][1], _brute(t[0], t[1], t[2], t[3] == 2, t[4], t[5], t[6]), True)
+
+
+def test_trees_built_queried_and_dropped_on_several_threads_at_once():
+    """The reference runs one task per chromosome on a thread pool, each with a tree of its own (mapper.hpp:238-246,
+    main.cpp:34-44). Eight threads here create, fill, build, query and drop indexes at the same time (ctypes releases
+    the GIL inside the library): the parked-object pool, the per-index streams and the process-wide state must keep
+    every task's answer its own."""
+    import threading
+    from binary_amd import IntervalIndex, capi
+    capi.load().bivx_release_pooled()
+    errors, results = [], {}
+
+    def worker(t):
+        try:
+            rng = np.random.default_rng(100 + t)
+            for rnd in range(6):
+                n = int(rng.integers(5_000, 120_000))
+                nchrom = int(rng.integers(1, 6))
+                chrom = rng.integers(0, nchrom, n).astype(np.uint32)
+                low = rng.integers(0, 2_000_000, n).astype(np.uint32)
+                high = (low + rng.integers(0, 3000, n)).astype(np.uint32)
+                typ = rng.integers(1, 4, n).astype(np.uint8) if rnd % 2 else None
+                q = 300
+                qc = rng.integers(0, nchrom, q).astype(np.uint32)
+                qlo = rng.integers(0, 2_000_000, q).astype(np.uint32)
+                qhi = (qlo + rng.integers(0, 4000, q)).astype(np.uint32)
+                with IntervalIndex(0) as idx:
+                    idx.insert_node(low, high, chrom, svtype=typ)
+                    idx.build()
+                    off, hits = idx.find_overlaps(qlo, qhi, qc)
+                exp = _brute(chrom, low, high, np.ones(n, bool), qc, qlo, qhi)
+                _check_csr(off, hits, exp, True)
+            results[t] = True
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not errors, errors
+    assert len(results) == 8
