@@ -6,7 +6,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
-LIB_PATH = os.path.join(_PKG, "libbivx.so")
+# BIVX_LIB: a variant build to load instead (tools/build_variant.sh; A/B measurements only)
+LIB_PATH = os.environ.get("BIVX_LIB") or os.path.join(_PKG, "libbivx.so")
 _SOURCES = ("scan.hip", "build.hip", "query.hip", "query_fused.hip", "query_pipe.hip", "prefix_device.h", "query_device.h", "wave_device.h", "capi.hip", "sharded.cpp", "common.h",
             "Makefile")
 
@@ -21,6 +22,8 @@ def _stale() -> bool:
 
 def build_lib(force: bool = False, jobs: int = 4) -> str:
     """Compile every HIP translation unit for gfx950 and link binary_amd/libbivx.so."""
+    if os.environ.get("BIVX_LIB"):
+        return LIB_PATH
     if force:
         subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
     if force or _stale():

@@ -45,6 +45,15 @@ constexpr uint32_t kRing = 8;                  // tile slots in LDS
 #ifndef BIVX_DEFER
 #define BIVX_DEFER 2
 #endif
+#ifndef BIVX_WSLEEP
+#define BIVX_WSLEEP 4   // s_sleep argument between two polls of a worker's wait in LDS (units of 64 cycles)
+#endif
+#ifndef BIVX_SSLEEP
+#define BIVX_SSLEEP 2   // ... between two passes of the service wavefront that made no progress
+#endif
+#ifndef BIVX_EXP
+#define BIVX_EXP 0      // experiments (WRONG RESULTS, timing and instruction counts only): 1 no id layout, 2 no id stream-out, 4 no keep slots
+#endif
 constexpr uint32_t kDefer = BIVX_DEFER;  // iterations between counting a slice and writing it out (experiments: 1, 3)
 static_assert(kDefer >= 1 && kDefer <= 3, "deferral depth");
 constexpr uint32_t kPStage = kDefer == 2 ? 320 : (640 / kDefer) & ~3u;   // ids per wavefront stage (there are two: a slice waits two iterations for its base)
@@ -132,7 +141,7 @@ __device__ __forceinline__ void lds_store(uint32_t *p, uint32_t x) {
 __device__ __forceinline__ void lds_wait_eq(const uint32_t *p, uint32_t x) {
   // (polls cost issue slots the other wavefronts of the SIMD could use: a wait of a few microseconds is not polled
   // every sixty nanoseconds)
-  while (lds_load(p) != x) __builtin_amdgcn_s_sleep(4);
+  while (lds_load(p) != x) __builtin_amdgcn_s_sleep(BIVX_WSLEEP);
 }
 
 // `n` ids from a wavefront's stage (16-byte aligned) to consecutive output slots: four per lane and instruction (the
@@ -284,14 +293,15 @@ __device__ __forceinline__ uint32_t coop_mask32(const uint2 *rec, uint32_t *keep
 
   {
     const uint32_t w0 = (al >> 1) | (npairs < 8u ? npairs : 8u) << 27 | (ql >> 16) << 31;
-    BIVX_COOP_ROUND(0, w0, true, rawA, rawB)
-    BIVX_COOP_ROUND(1, w0, true, rawA, rawB)
-    BIVX_COOP_ROUND(2, w0, true, rawA, rawB)
-    BIVX_COOP_ROUND(3, w0, true, rawA, rawB)
-    BIVX_COOP_ROUND(4, w0, true, rawA, rawB)
-    BIVX_COOP_ROUND(5, w0, true, rawA, rawB)
-    BIVX_COOP_ROUND(6, w0, true, rawA, rawB)
-    BIVX_COOP_ROUND(7, w0, true, rawA, rawB)
+    constexpr bool kk = (BIVX_EXP & 4) == 0;
+    BIVX_COOP_ROUND(0, w0, kk, rawA, rawB)
+    BIVX_COOP_ROUND(1, w0, kk, rawA, rawB)
+    BIVX_COOP_ROUND(2, w0, kk, rawA, rawB)
+    BIVX_COOP_ROUND(3, w0, kk, rawA, rawB)
+    BIVX_COOP_ROUND(4, w0, kk, rawA, rawB)
+    BIVX_COOP_ROUND(5, w0, kk, rawA, rawB)
+    BIVX_COOP_ROUND(6, w0, kk, rawA, rawB)
+    BIVX_COOP_ROUND(7, w0, kk, rawA, rawB)
   }
   const uint32_t raw = spread8(rawA) | spread8(rawB) << 1;
   const uint32_t wm = ((1u << n) - 1u) & ~(w.a - al);  // the window's own bits: [a - al, n); a - al is 0 or 1
@@ -448,7 +458,7 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
       }
     }
     if (!drawing && swept == drawn - 1) break;
-    if (!progress) __builtin_amdgcn_s_sleep(2);
+    if (!progress) __builtin_amdgcn_s_sleep(BIVX_SSLEEP);
   }
   // self-cleaning workspace: every service wavefront bumps `done` when its sweeps are over and its last ticket is
   // drawn; the one that sees gridDim.x - 1 knows nobody touches the words any more and zeroes them for the next
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
                             (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wpos0 >> 32)) << 32;
         uint32_t *const out = p->a.hits + wp;
         const uint32_t lim = cap > wp ? (cap - wp < pd.wtotal ? (uint32_t)(cap - wp) : pd.wtotal) : 0u;
-        stage_to_output(stage, out, lim, tid() & (kWave - 1));
+        if (!(BIVX_EXP & 2)) stage_to_output(stage, out, lim, tid() & (kWave - 1));
       }
     } else {
       // an unstaged slice kept (list offset, count) per lane in its stage; its ids are k_fill_slices' business
@@ -751,6 +761,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
       stage[3 * lane] = (uint32_t)lpos64;
       stage[3 * lane + 1] = (uint32_t)(lpos64 >> 32);
       stage[3 * lane + 2] = cnt;
+    } else if ((BIVX_EXP & 1) != 0) {
     } else if (!no_ids && path == 1) {  // the ids are in the wavefront's slab
       const uint2 *s2 = reinterpret_cast<const uint2 *>(slab_of_wave()) + ((qw_a & ~1u) - lbase);
       uint32_t *dst = stage + loff;

@@ -120,3 +120,111 @@ def test_gatherv_single_rank(tmp_path):
         assert torch.equal(g_off, off) and torch.equal(g_hits, hits) and qs.tolist() == [3] and hs.tolist() == [5]
     finally:
         dist.destroy_process_group()
+
+
+# ---- the bench's tree-free verification and the checksum that vouches for a gathered CSR (binary_amd/csr_check.py) -----
+
+def _dense_genome():
+    # the bench's generator on short "chromosomes", so that lists are a few ids long
+    lengths = np.array([40_000, 25_000, 9_000, 31_000, 5_000], dtype=np.int64)
+    return synth.gen_genome(3000, 2500, 1000, lengths=lengths), lengths
+
+
+def _oracle_csr(oracle_mod, data, chroms):
+    off, hits, _ = _rank_csr(oracle_mod, data, chroms)
+    return off, hits
+
+
+def test_csr_check_accepts_the_oracle_and_rejects_every_kind_of_damage(oracle):
+    from binary_amd import csr_check
+    data, lengths = _dense_genome()
+    off, hits = _oracle_csr(oracle, data, range(len(lengths)))
+    assert hits.size > 5000
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32))
+    args = (T(data["chrom"]), T(data["low"]), T(data["high"]), T(data["qchrom"]), T(data["qlow"]), T(data["qhigh"]))
+    v = csr_check.verify_shard(*args, torch.from_numpy(off), torch.from_numpy(hits), chunk=700)
+    assert v["ok"] and v["pairs"] == hits.size
+    gq, gi = np.arange(data["qlow"].size), np.arange(data["low"].size)
+    a = csr_check.checksum_csr(torch.from_numpy(off), torch.from_numpy(hits), torch.from_numpy(gq), torch.from_numpy(gi), chunk=333)
+    assert a == csr_check.checksum_csr_np(off, hits, gq, gi)
+    # order inside a list does not matter, content does
+    q = int(np.argmax(np.diff(off)))
+    h2 = hits.copy()
+    h2[off[q]:off[q + 1]] = h2[off[q]:off[q + 1]][::-1]
+    assert csr_check.checksum_csr(torch.from_numpy(off), torch.from_numpy(h2), torch.from_numpy(gq), torch.from_numpy(gi)) == a
+    assert csr_check.verify_shard(*args, torch.from_numpy(off), torch.from_numpy(h2))["ok"]
+    h3 = hits.copy()
+    h3[off[q]] = h3[off[q] + 1]          # an id twice (and one missing): counts still right
+    v3 = csr_check.verify_shard(*args, torch.from_numpy(off), torch.from_numpy(h3))
+    assert v3["counts_ok"] and not v3["distinct_ok"] and not v3["ok"]
+    assert csr_check.checksum_csr(torch.from_numpy(off), torch.from_numpy(h3), torch.from_numpy(gq), torch.from_numpy(gi)) != a
+    h4 = hits.copy()
+    h4[off[q]] = (h4[off[q]] + 1500) % data["low"].size   # a non-overlapping id
+    assert not csr_check.verify_shard(*args, torch.from_numpy(off), torch.from_numpy(h4))["pairs_ok"]
+    o5 = off.copy()
+    o5[q + 1] -= 1                        # a hit moved to the next query
+    assert not csr_check.verify_shard(*args, torch.from_numpy(o5), torch.from_numpy(hits))["counts_ok"]
+
+
+def _checksum_worker(rank, world, port, tmpdir):
+    """bench.py's N > 1 verification flow in miniature: every rank checksums its shard with GLOBAL ids, the sums are
+    all-reduced, rank 0 recomputes the checksum over the gathered CSR block by block and compares."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ivtree_oracle as oracle_mod
+        from binary_amd import csr_check
+        data, lengths = _dense_genome()
+        per_i, per_q = synth.split_by_length(3000, lengths), synth.split_by_length(2500, lengths)
+        assign = sharding.lpt_assign(sharding.chrom_work(per_i, per_q), world)
+        # a rank's shard as bench.py holds it: only its chromosomes, ids local to the shard
+        mine = synth.gen_genome(3000, 2500, 1000, lengths=lengths, chrom_ids=assign[rank])
+        off, hits = _oracle_csr(oracle_mod, mine, assign[rank])
+        gq = torch.from_numpy(csr_check.global_id_maps(assign[rank], per_q))
+        gi = torch.from_numpy(csr_check.global_id_maps(assign[rank], per_i))
+        s, x, n = csr_check.checksum_csr(torch.from_numpy(off), torch.from_numpy(hits), gq, gi)
+        t = torch.tensor([s & 0xFFFFFFFF, s >> 32, n], dtype=torch.int64)
+        dist.all_reduce(t)
+        xs = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(xs, torch.tensor([x & 0xFFFFFFFF, x >> 32], dtype=torch.int64))
+        tot_s = (int(t[0]) + (int(t[1]) << 32)) & 0xFFFFFFFFFFFFFFFF
+        tot_x = 0
+        for v in xs:
+            tot_x ^= int(v[0]) | (int(v[1]) << 32)
+        res = sharding.gatherv_csr(torch.from_numpy(off), torch.from_numpy(hits), dst=0)
+        if rank == 0:
+            g_off, g_hits, qs, hs = res
+            qd = np.concatenate([[0], np.cumsum(qs)])
+            gs = gx = gp = 0
+            for r in range(world):
+                rs, rx, rp = csr_check.checksum_csr(g_off[int(qd[r]):int(qd[r + 1]) + 1], g_hits,
+                                                    torch.from_numpy(csr_check.global_id_maps(assign[r], per_q)),
+                                                    torch.from_numpy(csr_check.global_id_maps(assign[r], per_i)))
+                gs, gx, gp = (gs + rs) & 0xFFFFFFFFFFFFFFFF, gx ^ rx, gp + rp
+            assert (gs, gx, gp) == (tot_s, tot_x, int(t[2]))
+            # ... and it is the whole genome's checksum, whatever the sharding
+            off_w, hits_w = _oracle_csr(oracle_mod, data, range(len(lengths)))
+            whole = csr_check.checksum_csr_np(off_w, hits_w, np.arange(2500), np.arange(3000))
+            assert whole == (gs, gx, gp)
+            # a damaged block is noticed
+            bad = g_hits.clone()
+            bad[-1] = bad[-2]
+            r = world - 1
+            rs, rx, _ = csr_check.checksum_csr(g_off[int(qd[r]):int(qd[r + 1]) + 1], bad,
+                                               torch.from_numpy(csr_check.global_id_maps(assign[r], per_q)),
+                                               torch.from_numpy(csr_check.global_id_maps(assign[r], per_i)))
+            assert (rs, rx) != csr_check.checksum_csr(g_off[int(qd[r]):int(qd[r + 1]) + 1], g_hits,
+                                                      torch.from_numpy(csr_check.global_id_maps(assign[r], per_q)),
+                                                      torch.from_numpy(csr_check.global_id_maps(assign[r], per_i)))[:2]
+            open(os.path.join(tmpdir, "ok"), "w").write("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gathered_checksum_equals_the_ranks_gloo(world, tmp_path, oracle):
+    port = _free_port()
+    mp.spawn(_checksum_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()
