@@ -1,5 +1,5 @@
-"""Tree-free checks of a CSR overlap result with torch tensor ops (bench.py and tests; never on the product path, and
-it does not touch the oracle): every per-query count against a sort + searchsorted count, every reported pair against
+"""Tree-free checks of a CSR overlap result with torch tensor ops (for bench.py and the tests; nothing on the query
+path calls this, and it uses no CPU tree): every per-query count against a sort + searchsorted count, every reported pair against
 the predicate, pairs distinct — together: the exact hit SET of every query (reference semantics:
 interval_tree.hpp:119-121, 306-334) — and SURVEY.md §8d's order-independent 64-bit checksum, sum and XOR of
 hash(global query id, global interval id), which lets ranks that hold different chromosomes vouch for a gathered CSR.

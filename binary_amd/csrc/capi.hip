@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "common.h"
@@ -89,6 +90,10 @@ struct bivx_index {
   };
   mutable std::mutex ws_mutex;
   mutable std::unordered_map<hipStream_t, Workspace> ws_of_stream;
+  // Caller streams on which device-pointer calls have read the built arrays since the last build: a rebuild (and
+  // bivx_clear) overwrites those arrays on idx->stream and must come after whatever is still running there. The
+  // query path pays one hash insert for it; the build waits for these streams, not for the whole device.
+  mutable std::unordered_set<hipStream_t> reader_streams;
   // error block of the kernels (IndexView::err): pinned host memory mapped into the device, so that every
   // synchronising entry point can look at it without a copy
   uint32_t *h_err = nullptr;  // host address
@@ -146,6 +151,18 @@ struct DeviceGuard {
     return BIVX_E_HIP;                                                \
   }
 
+// hipMalloc that gives the device memory of parked index objects (bivx_destroy keeps up to BIVX_INDEX_POOL of them with
+// their grow-only blocks, invisible to the caller) back before it reports failure: a build that fitted before an index
+// was dropped must still fit afterwards.
+extern "C" void bivx_release_pooled(void);
+hipError_t dev_malloc(void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();
+  bivx_release_pooled();
+  return hipMalloc(p, bytes);
+}
+
 // Temporaries of one call: everything allocated through it is handed back when it goes out of scope — to the
 // index's block cache when the block is small (the caller has synchronised its stream by then), else to hipFree.
 struct TempPool {
@@ -186,7 +203,7 @@ struct TempPool {
         idx->cache_bytes -= bytes;
       }
     }
-    if (!p) BIVX_HIP(hipMalloc(&p, bytes));
+    if (!p) BIVX_HIP(dev_malloc(&p, bytes));
     ptrs.emplace_back(p, bytes);
     *out = static_cast<T *>(p);
     return 0;
@@ -236,7 +253,7 @@ int ensure_block(bivx_index::DevBuf &b, size_t bytes) {
   b.p = nullptr;
   b.cap = 0;
   const size_t want = (bytes + 255) & ~(size_t)255;
-  BIVX_HIP(hipMalloc(&b.p, want ? want : 256));
+  BIVX_HIP(dev_malloc(&b.p, want ? want : 256));
   b.cap = want ? want : 256;
   return 0;
 }
@@ -275,6 +292,35 @@ int note_device_append(bivx_index *idx, hipStream_t s) {
   return 0;
 }
 
+// a device-pointer call is about to read the built index on the caller's stream `s`
+void note_reader(const bivx_index *idx, hipStream_t s) {
+  if (s == idx->stream) return;  // (ordered with the build by the stream itself)
+  std::lock_guard<std::mutex> lock(idx->ws_mutex);
+  idx->reader_streams.insert(s);
+}
+
+// Before the built arrays (or the append-order columns they were made from) are overwritten: every query, fill or
+// self-overlap call enqueued so far on a caller stream must have finished reading them. The streams are waited for one
+// by one (an idle stream costs a microsecond); a stream the caller has destroyed since has finished its work — its
+// stale handle is reported as invalid by the runtime and skipped.
+int wait_for_readers(bivx_index *idx) {
+  std::vector<hipStream_t> streams;
+  {
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    streams.assign(idx->reader_streams.begin(), idx->reader_streams.end());
+    idx->reader_streams.clear();
+  }
+  for (hipStream_t rs : streams) {
+    const hipError_t e = hipStreamSynchronize(rs);
+    if (e == hipSuccess) continue;
+    (void)hipGetLastError();
+    if (e == hipErrorInvalidHandle || e == hipErrorInvalidResourceHandle || e == hipErrorContextIsDestroyed) continue;
+    set_error("waiting for a caller stream that reads the index failed: %s", hipGetErrorString(e));
+    return BIVX_E_HIP;
+  }
+  return 0;
+}
+
 int ensure_capacity(bivx_index *idx, size_t need) {
   if (need <= idx->cap) return 0;
   if (need >= 0xFFFFFFFFull) {
@@ -287,10 +333,10 @@ int ensure_capacity(bivx_index *idx, size_t need) {
   uint32_t *c = nullptr, *l = nullptr, *h = nullptr;
   uint8_t *ty = nullptr;
   auto grow = [&]() -> int {
-    BIVX_HIP(hipMalloc((void **)&c, nc * sizeof(uint32_t)));
-    BIVX_HIP(hipMalloc((void **)&l, nc * sizeof(uint32_t)));
-    BIVX_HIP(hipMalloc((void **)&h, nc * sizeof(uint32_t)));
-    BIVX_HIP(hipMalloc((void **)&ty, nc));
+    BIVX_HIP(dev_malloc((void **)&c, nc * sizeof(uint32_t)));
+    BIVX_HIP(dev_malloc((void **)&l, nc * sizeof(uint32_t)));
+    BIVX_HIP(dev_malloc((void **)&h, nc * sizeof(uint32_t)));
+    BIVX_HIP(dev_malloc((void **)&ty, nc));
     BIVX_HIP(hipMemsetAsync(ty, 0, nc, idx->stream));
     if (idx->n) {
       // Earlier bivx_append_dev calls copy on the CALLER's streams, which idx->stream is not ordered after: wait
@@ -333,6 +379,15 @@ int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, con
   }
   if (n == 0) return 0;
   BIVX_GUARD(idx);
+  if (kind != hipMemcpyHostToDevice && s) {
+    // an append inside a stream capture would record its completion event as a graph node: the build can neither wait
+    // for it nor stay out of the caller's capture
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      set_error("bivx_append_dev: the stream is being captured; appends cannot be part of a graph");
+      return BIVX_E_STATE;
+    }
+  }
   BIVX_TRY(ensure_capacity(idx, idx->n + n));
   if (chrom)
     BIVX_HIP(hipMemcpyAsync(idx->d_chrom + idx->n, chrom, n * 4, kind, s));
@@ -803,6 +858,7 @@ int bivx_clear(bivx_index *idx) {
   if (idx->sharded) return sharded_clear(idx->sharded);
   BIVX_GUARD(idx);
   BIVX_HIP(hipStreamSynchronize(idx->stream));
+  BIVX_TRY(wait_for_readers(idx));  // (the general self-overlap call reads the appended columns the next appends overwrite)
   free_built(idx);
   if (idx->typed && idx->d_type && idx->n) {
     // the slots are reused by later appends: an untyped append into them only clears type bytes while `typed` is set,
@@ -833,6 +889,9 @@ int bivx_build(bivx_index *idx) {
     idx->ev_free.push_back(ev);
   }
   idx->ev_pending.clear();
+  // ... and calls that still read the arrays of the last build on caller streams must be through with them: the blocks
+  // are grow-only, a rebuild of the same size overwrites them in place
+  BIVX_TRY(wait_for_readers(idx));
   {
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     // on the build stream, which is synchronised before bivx_build returns (a plain hipMemset runs on the null
@@ -1110,6 +1169,7 @@ int bivx_fill_dev_f(const bivx_index *idx, const uint32_t *d_qchrom, const uint3
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
+  note_reader(idx, static_cast<hipStream_t>(stream));
   return launch_fill(view, d_qchrom, d_qlow, d_qhigh, q, d_offsets, d_hit_ids, static_cast<hipStream_t>(stream));
 }
 
@@ -1148,6 +1208,7 @@ int query_single_pass(const bivx_index *idx, const uint32_t *d_qchrom, const uin
   }
   BIVX_GUARD(idx);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  note_reader(idx, s);
   bool self_clean = false;
   if (!d_workspace) {  // the index's own per-stream workspace: no memset in front of the kernel
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
@@ -1163,7 +1224,7 @@ int query_single_pass(const bivx_index *idx, const uint32_t *d_qchrom, const uin
       }
       if (it == idx->ws_of_stream.end()) {
         void *p = nullptr;
-        BIVX_HIP(hipMalloc(&p, fused_workspace_bytes(q)));
+        BIVX_HIP(dev_malloc(&p, fused_workspace_bytes(q)));
         bivx_index::Workspace w;
         w.p = p;
         it = idx->ws_of_stream.emplace(s, w).first;
@@ -1217,6 +1278,7 @@ int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_of
                              d_hit_ids, hit_capacity, nullptr, nullptr, 0, stream, "bivx_self_overlaps_dev");
   BIVX_GUARD(idx);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  note_reader(idx, s);
   // the intervals as queries in slot order, once per build (on the index's stream, finished before anybody uses them)
   {
     std::lock_guard<std::mutex> lock(idx->self_mutex);
@@ -1248,7 +1310,7 @@ int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_of
       }
       if (fresh) {
         void *p = nullptr;
-        BIVX_HIP(hipMalloc(&p, fused_workspace_bytes(n)));
+        BIVX_HIP(dev_malloc(&p, fused_workspace_bytes(n)));
         bivx_index::Workspace w;
         w.p = p;
         w.needs_reset = true;
@@ -1263,7 +1325,7 @@ int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_of
         (void)hipFree(it->second.self_p);
         it->second.self_p = nullptr;
         it->second.self_cap = 0;
-        BIVX_HIP(hipMalloc(&it->second.self_p, self_bytes));
+        BIVX_HIP(dev_malloc(&it->second.self_p, self_bytes));
         it->second.self_cap = self_bytes;
       }
     }
@@ -1347,6 +1409,7 @@ int bivx_any_dev(const bivx_index *idx, const uint32_t *d_qchrom, const uint32_t
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
+  note_reader(idx, static_cast<hipStream_t>(stream));
   return launch_any(view_of(idx), d_qchrom, d_qlow, d_qhigh, q, d_first_id, static_cast<hipStream_t>(stream));
 }
 

@@ -46,10 +46,13 @@ constexpr uint32_t kRing = 8;                  // tile slots in LDS
 #define BIVX_DEFER 2
 #endif
 #ifndef BIVX_WSLEEP
-#define BIVX_WSLEEP 4   // s_sleep argument between two polls of a worker's wait in LDS (units of 64 cycles)
+#define BIVX_WSLEEP 16  // s_sleep argument between two polls of a worker's wait in LDS (units of 64 cycles)
 #endif
 #ifndef BIVX_SSLEEP
 #define BIVX_SSLEEP 2   // ... between two passes of the service wavefront that made no progress
+#endif
+#ifndef BIVX_COOP_DEPTH
+#define BIVX_COOP_DEPTH 2   // rounds of coop_mask32 whose loads are in flight together (1: load, wait, evaluate; 2 fits 64 registers)
 #endif
 #ifndef BIVX_EXP
 #define BIVX_EXP 0      // experiments (WRONG RESULTS, timing and instruction counts only): 1 no id layout, 2 no id stream-out, 4 no keep slots
@@ -263,22 +266,29 @@ __device__ __forceinline__ uint32_t coop_mask32(const uint2 *rec, uint32_t *keep
   uint32_t *const kbase = keep_of_wave + (lane & 0x38u);  // + rank * 64 + k: slot `rank` of the round's owner
   uint32_t rawA = 0, rawB = 0;  // the owner's bytes of its own round
 
-#define BIVX_COOP_ROUND(k, W0, KEEPIDS, OUTA, OUTB)                                                                   \
+// A round in two halves, so that the loads of several rounds can be in flight together (BIVX_COOP_DEPTH, default 2: the
+// round trips of a slice's eight rounds are what a worker's iteration mostly waits for — the kernel is bound by that
+// latency chain, not by instruction issue: profiles/r04_query_kernel_experiments.txt): LOAD fetches the owner's words
+// and issues the group's load, EVAL evaluates what arrived.
+#define BIVX_COOP_LOAD(k, W0)                                                                                          \
+  const uint32_t s0_##k = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(W0), 0x18 | ((k) << 5));                        \
+  const uint32_t s1_##k = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w.base, 0x18 | ((k) << 5));                     \
+  const uint32_t s2_##k = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w2, 0x18 | ((k) << 5));                         \
+  /* (the lanes whose pair lies in the window, as a lane mask straight from the comparison; what a lane that loads      \
+     nothing has in its registers is evaluated like the rest and masked off by it) */                                 \
+  const uint32_t np_##k = (s0_##k >> 27) & 15u;                                                                       \
+  const uint64_t live_##k = __builtin_amdgcn_uicmp(p, np_##k, 36);                                                    \
+  const uint32_t sql_##k = (s2_##k & 0xFFFFu) | (s0_##k >> 31) << 16;                                                 \
+  uint4 r_##k;                                                                                                        \
+  asm volatile("" : "=v"(r_##k.x), "=v"(r_##k.y), "=v"(r_##k.z), "=v"(r_##k.w));                                      \
+  if (p < np_##k) r_##k = *reinterpret_cast<const uint4 *>(rb + (((s0_##k & 0x7FFFFFFu) + p) << 4));
+
+#define BIVX_COOP_EVAL(k, KEEPIDS, OUTA, OUTB)                                                                        \
   {                                                                                                                   \
-    const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(W0), 0x18 | ((k) << 5));                          \
-    const uint32_t s1 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w.base, 0x18 | ((k) << 5));                       \
-    const uint32_t s2 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)w2, 0x18 | ((k) << 5));                           \
-    /* (the lanes whose pair lies in the window, as a lane mask straight from the comparison; what a lane that loads    \
-       nothing has in its registers is evaluated like the rest and masked off by it) */                               \
-    const uint32_t np_ = (s0 >> 27) & 15u;                                                                            \
-    const uint64_t live = __builtin_amdgcn_uicmp(p, np_, 36);                                                         \
-    uint4 r;                                                                                                          \
-    asm volatile("" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w));                                                    \
-    if (p < np_) r = *reinterpret_cast<const uint4 *>(rb + (((s0 & 0x7FFFFFFu) + p) << 4));                           \
-    const uint32_t sql = (s2 & 0xFFFFu) | (s0 >> 31) << 16, sqh = s2 >> 16;                                           \
-    const uint32_t la = (r.x - s1) & 0xFFFFu, lb = (r.z - s1) & 0xFFFFu;                                              \
-    const uint64_t hA = __builtin_amdgcn_uicmp(la, sqh, 37) & __builtin_amdgcn_uicmp(la + (r.x >> 16), sql, 35) & live; \
-    const uint64_t hB = __builtin_amdgcn_uicmp(lb, sqh, 37) & __builtin_amdgcn_uicmp(lb + (r.z >> 16), sql, 35) & live; \
+    const uint32_t sqh = s2_##k >> 16;                                                                                \
+    const uint32_t la = (r_##k.x - s1_##k) & 0xFFFFu, lb = (r_##k.z - s1_##k) & 0xFFFFu;                              \
+    const uint64_t hA = __builtin_amdgcn_uicmp(la, sqh, 37) & __builtin_amdgcn_uicmp(la + (r_##k.x >> 16), sql_##k, 35) & live_##k; \
+    const uint64_t hB = __builtin_amdgcn_uicmp(lb, sqh, 37) & __builtin_amdgcn_uicmp(lb + (r_##k.z >> 16), sql_##k, 35) & live_##k; \
     const uint32_t bA = (uint32_t)(hA >> gsh) & 0xFFu, bB = (uint32_t)(hB >> gsh) & 0xFFu;                            \
     if (p == (k)) {                                                                                                   \
       OUTA = bA;                                                                                                      \
@@ -286,22 +296,51 @@ __device__ __forceinline__ uint32_t coop_mask32(const uint2 *rec, uint32_t *keep
     }                                                                                                                 \
     if (KEEPIDS) {                                                                                                    \
       const uint32_t ra = (uint32_t)__popc(bA & below) + (uint32_t)__popc(bB & below), rbk = ra + ((bA >> p) & 1u);   \
-      if (((bA >> p) & 1u) != 0u && ra < KEEP) kbase[ra * kWave + (k)] = r.y;                                          \
-      if (((bB >> p) & 1u) != 0u && rbk < KEEP) kbase[rbk * kWave + (k)] = r.w;                                        \
+      if (((bA >> p) & 1u) != 0u && ra < KEEP) kbase[ra * kWave + (k)] = r_##k.y;                                      \
+      if (((bB >> p) & 1u) != 0u && rbk < KEEP) kbase[rbk * kWave + (k)] = r_##k.w;                                    \
     }                                                                                                                 \
   }
+
+// the eight rounds with BIVX_COOP_DEPTH loads in flight
+#if BIVX_COOP_DEPTH == 1
+#define BIVX_COOP_ROUNDS(W0, KEEPIDS, OUTA, OUTB)                                                            \
+  { BIVX_COOP_LOAD(0, W0) BIVX_COOP_EVAL(0, KEEPIDS, OUTA, OUTB) } { BIVX_COOP_LOAD(1, W0) BIVX_COOP_EVAL(1, KEEPIDS, OUTA, OUTB) } \
+  { BIVX_COOP_LOAD(2, W0) BIVX_COOP_EVAL(2, KEEPIDS, OUTA, OUTB) } { BIVX_COOP_LOAD(3, W0) BIVX_COOP_EVAL(3, KEEPIDS, OUTA, OUTB) } \
+  { BIVX_COOP_LOAD(4, W0) BIVX_COOP_EVAL(4, KEEPIDS, OUTA, OUTB) } { BIVX_COOP_LOAD(5, W0) BIVX_COOP_EVAL(5, KEEPIDS, OUTA, OUTB) } \
+  { BIVX_COOP_LOAD(6, W0) BIVX_COOP_EVAL(6, KEEPIDS, OUTA, OUTB) } { BIVX_COOP_LOAD(7, W0) BIVX_COOP_EVAL(7, KEEPIDS, OUTA, OUTB) }
+#elif BIVX_COOP_DEPTH == 2
+#define BIVX_COOP_ROUNDS(W0, KEEPIDS, OUTA, OUTB)                                                            \
+  {                                                                                                          \
+    BIVX_COOP_LOAD(0, W0) BIVX_COOP_LOAD(1, W0) BIVX_COOP_EVAL(0, KEEPIDS, OUTA, OUTB)                       \
+    BIVX_COOP_LOAD(2, W0) BIVX_COOP_EVAL(1, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(3, W0) BIVX_COOP_EVAL(2, KEEPIDS, OUTA, OUTB) \
+    BIVX_COOP_LOAD(4, W0) BIVX_COOP_EVAL(3, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(5, W0) BIVX_COOP_EVAL(4, KEEPIDS, OUTA, OUTB) \
+    BIVX_COOP_LOAD(6, W0) BIVX_COOP_EVAL(5, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(7, W0) BIVX_COOP_EVAL(6, KEEPIDS, OUTA, OUTB) \
+    BIVX_COOP_EVAL(7, KEEPIDS, OUTA, OUTB)                                                                   \
+  }
+#elif BIVX_COOP_DEPTH == 3
+#define BIVX_COOP_ROUNDS(W0, KEEPIDS, OUTA, OUTB)                                                            \
+  {                                                                                                          \
+    BIVX_COOP_LOAD(0, W0) BIVX_COOP_LOAD(1, W0) BIVX_COOP_LOAD(2, W0) BIVX_COOP_EVAL(0, KEEPIDS, OUTA, OUTB) \
+    BIVX_COOP_LOAD(3, W0) BIVX_COOP_EVAL(1, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(4, W0) BIVX_COOP_EVAL(2, KEEPIDS, OUTA, OUTB) \
+    BIVX_COOP_LOAD(5, W0) BIVX_COOP_EVAL(3, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(6, W0) BIVX_COOP_EVAL(4, KEEPIDS, OUTA, OUTB) \
+    BIVX_COOP_LOAD(7, W0) BIVX_COOP_EVAL(5, KEEPIDS, OUTA, OUTB) BIVX_COOP_EVAL(6, KEEPIDS, OUTA, OUTB)      \
+    BIVX_COOP_EVAL(7, KEEPIDS, OUTA, OUTB)                                                                   \
+  }
+#else  // 4
+#define BIVX_COOP_ROUNDS(W0, KEEPIDS, OUTA, OUTB)                                                            \
+  {                                                                                                          \
+    BIVX_COOP_LOAD(0, W0) BIVX_COOP_LOAD(1, W0) BIVX_COOP_LOAD(2, W0) BIVX_COOP_LOAD(3, W0)                  \
+    BIVX_COOP_EVAL(0, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(4, W0) BIVX_COOP_EVAL(1, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(5, W0) \
+    BIVX_COOP_EVAL(2, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(6, W0) BIVX_COOP_EVAL(3, KEEPIDS, OUTA, OUTB) BIVX_COOP_LOAD(7, W0) \
+    BIVX_COOP_EVAL(4, KEEPIDS, OUTA, OUTB) BIVX_COOP_EVAL(5, KEEPIDS, OUTA, OUTB)                            \
+    BIVX_COOP_EVAL(6, KEEPIDS, OUTA, OUTB) BIVX_COOP_EVAL(7, KEEPIDS, OUTA, OUTB)                            \
+  }
+#endif
 
   {
     const uint32_t w0 = (al >> 1) | (npairs < 8u ? npairs : 8u) << 27 | (ql >> 16) << 31;
     constexpr bool kk = (BIVX_EXP & 4) == 0;
-    BIVX_COOP_ROUND(0, w0, kk, rawA, rawB)
-    BIVX_COOP_ROUND(1, w0, kk, rawA, rawB)
-    BIVX_COOP_ROUND(2, w0, kk, rawA, rawB)
-    BIVX_COOP_ROUND(3, w0, kk, rawA, rawB)
-    BIVX_COOP_ROUND(4, w0, kk, rawA, rawB)
-    BIVX_COOP_ROUND(5, w0, kk, rawA, rawB)
-    BIVX_COOP_ROUND(6, w0, kk, rawA, rawB)
-    BIVX_COOP_ROUND(7, w0, kk, rawA, rawB)
+    BIVX_COOP_ROUNDS(w0, kk, rawA, rawB)
   }
   const uint32_t raw = spread8(rawA) | spread8(rawB) << 1;
   const uint32_t wm = ((1u << n) - 1u) & ~(w.a - al);  // the window's own bits: [a - al, n); a - al is 0 or 1
@@ -319,17 +358,12 @@ __device__ __forceinline__ uint32_t coop_mask32(const uint2 *rec, uint32_t *keep
     uint32_t rawC = 0, rawD = 0;
     const uint32_t np2 = npairs > 8u ? npairs - 8u : 0u;
     const uint32_t w0 = ((al >> 1) + 8u) | np2 << 27 | (ql >> 16) << 31;
-    BIVX_COOP_ROUND(0, w0, false, rawC, rawD)
-    BIVX_COOP_ROUND(1, w0, false, rawC, rawD)
-    BIVX_COOP_ROUND(2, w0, false, rawC, rawD)
-    BIVX_COOP_ROUND(3, w0, false, rawC, rawD)
-    BIVX_COOP_ROUND(4, w0, false, rawC, rawD)
-    BIVX_COOP_ROUND(5, w0, false, rawC, rawD)
-    BIVX_COOP_ROUND(6, w0, false, rawC, rawD)
-    BIVX_COOP_ROUND(7, w0, false, rawC, rawD)
+    BIVX_COOP_ROUNDS(w0, false, rawC, rawD)
     m |= ((spread8(rawC) | spread8(rawD) << 1) << 16) & wm;
   }
-#undef BIVX_COOP_ROUND
+#undef BIVX_COOP_ROUNDS
+#undef BIVX_COOP_LOAD
+#undef BIVX_COOP_EVAL
   return m;
 }
 

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_reduce(const uint32_t *__
   __shared__ OutT lds[kScanThreads / kWave];
   const size_t base = (size_t)blockIdx.x * kScanTile;
   OutT acc = 0;
-  if (base + kScanTile <= n) {  // a full tile: two 16-byte loads per thread (order is irrelevant for a sum)
+  if (base + kScanTile <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {  // a full tile of an aligned array: two 16-byte loads per thread (order is irrelevant for a sum)
     const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
     const uint4 a = p[threadIdx.x], b = p[kScanThreads + threadIdx.x];
     acc = (OutT)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_scan(const uint32_t *__re
   __shared__ OutT lds[kScanThreads / kWave];
   const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;  // blocked
   uint32_t v[kScanItems];
-  if (base + kScanItems <= n) {
+  if (base + kScanItems <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
     const uint4 a = *reinterpret_cast<const uint4 *>(in + base);
     const uint4 b = *reinterpret_cast<const uint4 *>(in + base + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;

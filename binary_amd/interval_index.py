@@ -69,6 +69,12 @@ class IntervalIndex:
 
     __del__ = close
 
+    @staticmethod
+    def release_pooled() -> None:
+        """Frees the index objects bivx_destroy parked for the next bivx_create (their device blocks, pinned blocks and
+        streams; include/bivx.h, bivx_release_pooled). The library does this itself when a device allocation fails."""
+        capi.load().bivx_release_pooled()
+
     def __enter__(self):
         return self
 

@@ -38,13 +38,14 @@ namespace sv2nl {
       auto text = [&](const char *tag) { return vcf::get_info_field<char>(tag, hdr, rec); };
       svtype = text("SVTYPE");
       const bool bnd = svtype == "BND";
-      chr2 = bnd || svtype == "TRA" ? text("CHR2") : std::string();
-      strand1 = strand2 = true;
+      // As in the reference (vcf_info.cpp:14-31) the object is updated in place, record after record: chr2 and the strands
+      // keep what the record before left there when this one does not set them (an INV line without STRAND tags).
+      if (bnd || svtype == "TRA") chr2 = text("CHR2");
       if (svtype == "INV") {
         try {  // ONE block for both: without STRAND1 the second tag is not looked at
           strand1 = text("STRAND1") == "+";
           strand2 = text("STRAND2") == "+";
-        } catch (...) {  // files without strands: both stay '+', as in the reference
+        } catch (...) {  // (files without strands: both stay '+' from the first record on)
         }
       }
       const char *end_tag = bnd ? "POS2" : source == "nls" ? "SVEND" : "END";

@@ -358,7 +358,8 @@ namespace binary::parser::vcf {
   };
 
   /// One record: chrom, 0-based pos, rlen, and the info field; bound to the open file it came from, next() moves it on.
-  /// Copies are deep (the info field is cloned) and stay bound to the same file position as their source.
+  /// A copy takes the five value fields only (the reference's clone(), vcf.hpp:297-303: chrom, pos, rlen, source, a deep
+  /// copy of the info field): it is detached from the file — "past the end", and next() on it throws.
   template <InfoFieldConcept InfoType> class BaseVcfRecord {
   public:
     using info_type = InfoType;
@@ -370,12 +371,14 @@ namespace binary::parser::vcf {
       next();
     }
     BaseVcfRecord(BaseVcfRecord const &o)
-        : data_{o.data_}, eof_{o.eof_}, chrom{o.chrom}, pos{o.pos}, rlen{o.rlen}, source_{o.source_},
-          info{std::make_unique<InfoType>(*o.info)} {}
-    auto operator=(BaseVcfRecord const &o) -> BaseVcfRecord & {
+        : chrom{o.chrom}, pos{o.pos}, rlen{o.rlen}, source_{o.source_}, info{std::make_unique<InfoType>(*o.info)} {}
+    auto operator=(BaseVcfRecord const &o) -> BaseVcfRecord & {  // (the five fields; this record's binding stays as it is)
       if (this != &o) {
-        BaseVcfRecord tmp(o);
-        *this = std::move(tmp);
+        chrom = o.chrom;
+        pos = o.pos;
+        rlen = o.rlen;
+        source_ = o.source_;
+        info = std::make_unique<InfoType>(*o.info);
       }
       return *this;
     }

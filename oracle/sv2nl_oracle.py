@@ -70,7 +70,7 @@ def read_vcf(path: str, source: str):
             if line.startswith("#"):
                 continue
             try:
-                recs.append(_parse_record(line, source, types))
+                recs.append(_parse_record(line, source, types, recs[-1] if recs else None))
             except VcfReaderError as e:
                 err = str(e)
                 break
@@ -97,11 +97,15 @@ def _info(kv, types, tag, want):
     return kv[tag]
 
 
-def _parse_record(line, source, types):
+def _parse_record(line, source, types, prev=None):
     f = line.split("\t")
     if len(f) < 8:
         raise VcfReaderError("Failed to read line in vcf ")
     r = Rec()
+    if prev is not None:
+        # vcf_info.cpp:9-43 updates ONE info object in place, record after record: what a record does not set (the strands
+        # of an INV line without STRAND tags, CHR2 of a record that is neither TRA nor BND) is what the record before it left there
+        r.strand1, r.strand2, r.chr2 = prev.strand1, prev.strand2, prev.chr2
     r.chrom = f[0]
     r.pos = (int(f[1]) - 1) & 0xFFFFFFFF
     kv = {}

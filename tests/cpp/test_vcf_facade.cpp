@@ -102,6 +102,28 @@ static void parser_cases(const std::string &gz, const std::string &plain) {
     CHECK_EQ(it->pos, 93567288u - 1u);
     CHECK_EQ(it->info->svend, 7705262u);
   }
+  {  // a copied record is DETACHED, as the reference's clone() leaves it (vcf.hpp:246-250,297-303): the five value fields,
+     // no file binding ("past the end"; next() throws); assigning to a bound record leaves its binding alone
+    auto it = vcf_ranges.begin();
+    VcfRecord copy(*it);
+    CHECK_EQ(copy.chrom, "chr10");
+    CHECK_EQ(copy.pos, 93567288u - 1u);
+    CHECK_EQ(copy.info->svtype, "TRA");
+    CHECK(copy == *it);
+    CHECK(copy.eof_);
+    CHECK_THROWS(copy.next());
+    auto it2 = vcf_ranges.begin();
+    VcfRecord bound(std::move(const_cast<VcfRecord &>(*it2.operator->())));  // a move keeps the binding
+    CHECK(!bound.eof_);
+    VcfRecord other;
+    other.chrom = "chrZ";
+    bound = other;
+    CHECK_EQ(bound.chrom, "chrZ");
+    CHECK(!bound.eof_);
+    bound.next();  // still reads the file it was bound to: the second record
+    CHECK_EQ(bound.chrom, "chr10");
+    CHECK_EQ(bound.pos, 93567289u - 1u);
+  }
   {  // ranges / views (:103-128)
     static_assert(std::forward_iterator<VcfRanges<VcfRecord>::iterator>);
     static_assert(std::ranges::input_range<VcfRanges<VcfRecord>>);

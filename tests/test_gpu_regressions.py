@@ -356,3 +356,51 @@ def test_trees_built_queried_and_dropped_on_several_threads_at_once():
         th.join(timeout=600)
     assert not errors, errors
     assert len(results) == 8
+
+
+def test_rebuild_waits_for_queries_still_running_on_caller_streams():
+    """bivx_build overwrote the (grow-only, reused) index blocks on its own stream while device-pointer queries
+    enqueued on CALLER streams were still reading them. A long asynchronous query on a side stream, then at once clear +
+    append of different data of the same size + build: the first query's CSR must be the FIRST data set's answer."""
+    import torch
+    from binary_amd import IntervalIndex, synth
+    dev = torch.device("cuda:0")
+    to = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev)
+    n, q = 4_000_000, 6_000_000
+    L = 60_000_000
+    low1, high1 = synth.gen_intervals(n, L, 1000, 1)
+    low2, high2 = synth.gen_intervals(n, L, 1000, 2)      # same size, other intervals: the rebuild reuses every block
+    qlo, qhi = synth.gen_range_queries(q, L, 1000, 3)
+    d_l1, d_h1, d_l2, d_h2, d_ql, d_qh = (to(x) for x in (low1, high1, low2, high2, qlo, qhi))
+    side = torch.cuda.Stream(device=dev)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(d_l1, d_h1)
+        idx.build()
+        off_ref = torch.empty(q + 1, dtype=torch.int64, device=dev)
+        idx.count_overlaps_device(d_ql, d_qh, offsets=off_ref)
+        H = int(off_ref[-1].item())
+        hits_ref = torch.empty(H, dtype=torch.int32, device=dev)
+        idx.query_device(d_ql, d_qh, off_ref, hits_ref)
+        torch.cuda.synchronize()
+        for trial in range(3):
+            off = torch.full_like(off_ref, -1)
+            hits = torch.full_like(hits_ref, -1)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                for _ in range(4):                       # ~1.5 ms of queries in flight on the side stream
+                    idx.query_device(d_ql, d_qh, off, hits)
+            idx.clear()                                  # (host returns at once: nothing is synchronised by the caller)
+            idx.insert_node(d_l2 if trial % 2 == 0 else d_l1, d_h2 if trial % 2 == 0 else d_h1)
+            idx.build()
+            side.synchronize()
+            idx.stream_status(side.cuda_stream)
+            if trial % 2 == 0:
+                assert torch.equal(off, off_ref) and torch.equal(hits, hits_ref), "a rebuild overtook a running query"
+                # ... and the rebuilt index answers for the second set
+                off2 = torch.empty_like(off_ref)
+                idx.count_overlaps_device(d_ql, d_qh, offsets=off2)
+                assert not torch.equal(off2, off_ref)
+                del off2
+            else:
+                pass  # (the running queries read set 2 here; the rebuild restores set 1 for the next trial)
+            del off, hits
