@@ -10,8 +10,8 @@ import os
 from ._build import LIB_PATH
 
 BIVX_NO_HIT = 0xFFFFFFFF
-E_INVALID, E_HIP, E_NOMEM, E_STATE, E_RANGE, E_TIMEOUT = -1, -2, -3, -4, -5, -6
-ABI_VERSION = 0x00020002
+E_INVALID, E_HIP, E_NOMEM, E_STATE, E_RANGE, E_TIMEOUT, E_COMM = -1, -2, -3, -4, -5, -6, -7
+ABI_VERSION = 0x00020003
 
 EXPORTS = (
     "bivx_abi_version", "bivx_last_error", "bivx_create", "bivx_create_sharded", "bivx_num_devices", "bivx_device_of_chrom", "bivx_destroy", "bivx_device", "bivx_append",
@@ -20,6 +20,7 @@ EXPORTS = (
     "bivx_fill_dev", "bivx_query_workspace_bytes", "bivx_query_dev", "bivx_sort_hits_dev", "bivx_any", "bivx_any_dev", "bivx_get_stats",
     "bivx_count_f", "bivx_fill_f", "bivx_count_dev_f", "bivx_fill_dev_f", "bivx_query_dev_f", "bivx_query_dev_s", "bivx_query_dev_u",
     "bivx_find_overlaps", "bivx_free", "bivx_self_overlaps_dev", "bivx_stream_status", "bivx_query_kernel_name", "bivx_debug_corrupt_workspace", "bivx_release_pooled",
+    "bivx_query_sharded_dev",
 )
 
 
@@ -42,6 +43,12 @@ class Stats(C.Structure):
     _fields_ = [("n_intervals", C.c_uint64), ("n_chroms", C.c_uint32), ("n_segments", C.c_uint32),
                 ("n_cells", C.c_uint64), ("index_bytes", C.c_uint64), ("staging_bytes", C.c_uint64),
                 ("build_ms", C.c_double), ("prefix_timeouts", C.c_uint64)]
+
+
+class ShardedResult(C.Structure):
+    """bivx_sharded_result (include/bivx.h): the gathered device-resident CSR of bivx_query_sharded_dev."""
+    _fields_ = [("d_offsets", C.c_void_p), ("d_hit_ids", C.c_void_p), ("d_query_of_row", C.c_void_p),
+                ("rows", C.c_uint64), ("total", C.c_uint64), ("device", C.c_int), ("used_rccl", C.c_int)]
 
 
 _lib = None
@@ -108,6 +115,7 @@ def load() -> C.CDLL:
     L.bivx_query_dev_s.argtypes = [vp, u32p, u32p, u32p, sz, fp, C.c_int, u64p, u32p, C.c_uint64, vp, sz, vp]
     L.bivx_self_overlaps_dev.argtypes = [vp, C.c_int, u64p, u32p, C.c_uint64, vp]
     L.bivx_query_dev_u.argtypes = [vp, u32p, u32p, u32p, sz, fp, u64p, u32p, u32p, C.c_uint64, u64p, vp, sz, vp]
+    L.bivx_query_sharded_dev.argtypes = [vp, u32p, u32p, u32p, sz, C.c_int, C.POINTER(ShardedResult)]
     if L.bivx_abi_version() >> 16 != ABI_VERSION >> 16:
         raise ImportError("libbivx.so ABI major version mismatch")
     _lib = L

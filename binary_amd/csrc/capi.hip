@@ -1780,6 +1780,20 @@ int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow
   return 0;
 }
 
+int bivx_query_sharded_dev(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                           size_t q, int sort_by_id, bivx_sharded_result *out) {
+  if (!idx || !out) {
+    set_error("bivx_query_sharded_dev: null argument");
+    return BIVX_E_INVALID;
+  }
+  if (!idx->sharded) {
+    set_error("bivx_query_sharded_dev: not a sharded handle (bivx_create_sharded); a single-device index answers "
+              "device-resident batches with bivx_query_dev_s");
+    return BIVX_E_STATE;
+  }
+  return sharded_query_dev(idx->sharded, qchrom, qlow, qhigh, q, sort_by_id, out);
+}
+
 int bivx_get_stats(const bivx_index *idx, bivx_stats *out) {
   if (!idx || !out) {
     set_error("bivx_get_stats: null argument");

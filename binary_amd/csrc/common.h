@@ -111,6 +111,9 @@ int sharded_fill(const ShardedState *st, const uint32_t *qchrom, const uint32_t 
 int sharded_any(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                 size_t q, uint32_t *first_id_out);
 void sharded_stats(const ShardedState *st, bivx_stats *out);
+// the gathered device-resident CSR (bivx_query_sharded_dev)
+int sharded_query_dev(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                      size_t q, int sort_by_id, bivx_sharded_result *out);
 
 // ---- scan.hip ---------------------------------------------------------------------------------------
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = total. scratch: scan_scratch_bytes(n).

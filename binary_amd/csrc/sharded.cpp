@@ -14,11 +14,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <rccl/rccl.h>
 
 #include "common.h"
 
@@ -36,6 +39,21 @@ struct ShardedState {
   std::vector<uint32_t> chrom_shard;         // by_chrom: chromosome -> shard (0xFFFFFFFF: no interval there)
   std::vector<std::vector<uint32_t>> gid;    // by_chrom: shard-local id -> global id
   double build_ms = 0.0;
+  // ---- bivx_query_sharded_dev: the shards' CSRs gathered into devices[0]'s memory over RCCL ----------------------
+  struct Buf {  // grow-only device block
+    void *p = nullptr;
+    size_t cap = 0;
+  };
+  struct ShardDev {
+    hipStream_t stream = nullptr;   // on the shard's device: its queries, its id mapping and its side of the exchange
+    Buf q, off, hits, gid, sizes;   // the shard's sub-batch, its CSR, its local -> global id table, (queries, ids) x devices
+    size_t gid_n = 0;               // ids of the uploaded table (0: not uploaded since the last build)
+  };
+  mutable std::vector<ShardDev> dev;
+  mutable std::vector<ncclComm_t> comms;  // ncclCommInitAll over the handle's devices (all different), made on first use
+  mutable bool comm_tried = false;
+  mutable Buf out_off, out_hits, out_rows;  // the gathered CSR and its row -> query map, on devices[0]
+  mutable std::mutex dev_mutex;             // one gathered call at a time: the buffers above are the handle's
 };
 
 namespace {
@@ -174,8 +192,13 @@ static int create_impl(ShardedState **out, const int *devices, int ndev) {
   return 0;
 }
 
+static void release_dev_state(ShardedState *st);
 void sharded_destroy(ShardedState *st) {
   if (!st) return;
+  try {
+    release_dev_state(st);
+  } catch (...) {
+  }
   for (auto *p : st->shard) bivx_destroy(p);
   delete st;
 }
@@ -289,6 +312,7 @@ static int build_impl(ShardedState *st) {
   }));
   st->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (st->by_chrom) st->gid = std::move(ids);
+  for (auto &d : st->dev) d.gid_n = 0;  // (the id tables uploaded for bivx_query_sharded_dev belong to the last build)
   st->nchrom = nchrom;
   st->ntypes = st->typed ? max_type + 1 : 1;
   st->built = true;
@@ -441,6 +465,304 @@ static int any_impl(const ShardedState *st, const uint32_t *qchrom, const uint32
   });
 }
 
+
+// ---- bivx_query_sharded_dev: every shard answers on its device, RCCL gathers the CSRs into devices[0] --------------------
+
+namespace {
+
+#define BIVX_NCCL(call)                                                                                      \
+  do {                                                                                                       \
+    ncclResult_t bivx_n_ = (call);                                                                           \
+    if (bivx_n_ != ncclSuccess) {                                                                            \
+      set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(bivx_n_), __FILE__, __LINE__);            \
+      return BIVX_E_COMM;                                                                                    \
+    }                                                                                                        \
+  } while (0)
+
+struct OnDevice {  // the calling thread's current device for a scope
+  int prev = -1;
+  bool ok = false;
+  explicit OnDevice(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = prev == dev || hipSetDevice(dev) == hipSuccess;
+  }
+  ~OnDevice() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int grow(ShardedState::Buf &b, size_t bytes) {  // (the caller is on the block's device; nothing of the old block is in use)
+  if (b.p && bytes <= b.cap) return 0;
+  (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
+  BIVX_HIP(hipMalloc(&b.p, want));
+  b.cap = want;
+  return 0;
+}
+
+// shard-local ids -> the handle's global append-order ids
+__global__ __launch_bounds__(256) void k_map_ids(uint32_t *__restrict__ hits, uint64_t n, const uint32_t *__restrict__ gid) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) hits[i] = gid[hits[i]];
+}
+
+// the gathered offsets: block r arrived as the shard's own prefix sums (from 0); it begins hdisp[r] ids into the result
+__global__ __launch_bounds__(256) void k_rebase_offsets(uint64_t *__restrict__ off, const uint64_t *__restrict__ qdisp,
+                                                        const uint64_t *__restrict__ hdisp, uint32_t nshards, uint64_t rows,
+                                                        uint64_t total) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == rows) off[rows] = total;
+  if (i >= rows) return;
+  uint32_t r = 0;
+  while (r + 1 < nshards && qdisp[r + 1] <= i) ++r;
+  off[i] += hdisp[r];
+}
+
+int ensure_dev_state(const ShardedState *st) {
+  const size_t k = st->shard.size();
+  if (st->dev.size() != k) st->dev.resize(k);
+  for (size_t s = 0; s < k; ++s) {
+    if (st->dev[s].stream) continue;
+    OnDevice g(st->devices[s]);
+    if (!g.ok) {
+      set_error("hipSetDevice(%d) failed", st->devices[s]);
+      return BIVX_E_HIP;
+    }
+    BIVX_HIP(hipStreamCreateWithFlags(&st->dev[s].stream, hipStreamNonBlocking));
+  }
+  if (!st->comm_tried) {
+    st->comm_tried = true;
+    std::vector<int> d = st->devices;
+    std::sort(d.begin(), d.end());
+    const bool distinct = std::adjacent_find(d.begin(), d.end()) == d.end();
+    if (distinct) {  // (RCCL refuses a device twice in one communicator: such handles copy device to device)
+      st->comms.assign(k, nullptr);
+      const ncclResult_t e = ncclCommInitAll(st->comms.data(), (int)k, st->devices.data());
+      if (e != ncclSuccess) {
+        st->comms.clear();
+        st->comm_tried = false;
+        set_error("ncclCommInitAll over %zu devices failed: %s", k, ncclGetErrorString(e));
+        return BIVX_E_COMM;
+      }
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+static int query_dev_impl(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                          size_t q, int sort_by_id, bivx_sharded_result *out) {
+  if (!out || (q && (!qlow || !qhigh))) {
+    set_error("bivx_query_sharded_dev: null argument");
+    return BIVX_E_INVALID;
+  }
+  std::memset(out, 0, sizeof(*out));
+  if (!sharded_is_built(st)) {
+    set_error("bivx_query_sharded_dev: index not built (call bivx_build after the last append)");
+    return BIVX_E_STATE;
+  }
+  std::lock_guard<std::mutex> lock(st->dev_mutex);
+  BIVX_TRY(ensure_dev_state(st));
+  const size_t k = st->shard.size();
+  Route r;
+  BIVX_TRY(route(st, qchrom, q, r));
+  if (st->by_chrom) {
+    // a query on a chromosome no device holds still gets its (empty) row: the first shard answers it
+    std::vector<uint32_t> extra;
+    for (size_t i = 0; i < q; ++i) {
+      const uint32_t c = qchrom ? qchrom[i] : 0u;
+      if (c >= st->chrom_shard.size() || st->chrom_shard[c] == 0xFFFFFFFFu) extra.push_back((uint32_t)i);
+    }
+    if (!extra.empty()) {
+      std::vector<uint32_t> merged(r.qs[0].size() + extra.size());
+      std::merge(r.qs[0].begin(), r.qs[0].end(), extra.begin(), extra.end(), merged.begin());
+      r.qs[0].swap(merged);
+    }
+  }
+  // 1. every shard answers its queries on its own device and stream: count, size, single pass, ids made global
+  std::vector<uint64_t> nq(k, 0), nh(k, 0);
+  BIVX_TRY(on_every_shard(st, [&](size_t s) -> int {
+    ShardedState::ShardDev &d = st->dev[s];
+    OnDevice g(st->devices[s]);
+    if (!g.ok) {
+      set_error("hipSetDevice(%d) failed", st->devices[s]);
+      return BIVX_E_HIP;
+    }
+    const size_t m = r.qs[s].size();
+    nq[s] = m;
+    BIVX_TRY(grow(d.sizes, 2 * sizeof(uint64_t) * (k + 1)));
+    BIVX_TRY(grow(d.off, (m + 1) * sizeof(uint64_t)));
+    if (m == 0) {
+      BIVX_HIP(hipMemsetAsync(d.off.p, 0, sizeof(uint64_t), d.stream));
+      BIVX_HIP(hipStreamSynchronize(d.stream));
+      return 0;
+    }
+    SubBatch b;
+    std::vector<uint32_t> iaux;
+    gather(st, s, r.qs[s], qchrom, qlow, qhigh, nullptr, b, iaux);
+    BIVX_TRY(grow(d.q, 3 * m * sizeof(uint32_t)));
+    uint32_t *dq = static_cast<uint32_t *>(d.q.p);
+    if (qchrom) BIVX_HIP(hipMemcpyAsync(dq, b.c.data(), m * 4, hipMemcpyHostToDevice, d.stream));
+    BIVX_HIP(hipMemcpyAsync(dq + m, b.lo.data(), m * 4, hipMemcpyHostToDevice, d.stream));
+    BIVX_HIP(hipMemcpyAsync(dq + 2 * m, b.hi.data(), m * 4, hipMemcpyHostToDevice, d.stream));
+    uint64_t *doff = static_cast<uint64_t *>(d.off.p);
+    BIVX_TRY(bivx_count_dev(st->shard[s], qchrom ? dq : nullptr, dq + m, dq + 2 * m, m, doff, d.stream));
+    uint64_t total = 0;
+    BIVX_HIP(hipMemcpyAsync(&total, doff + m, sizeof(uint64_t), hipMemcpyDeviceToHost, d.stream));
+    BIVX_HIP(hipStreamSynchronize(d.stream));  // (also: the host vectors of the sub-batch may go)
+    BIVX_TRY(bivx_stream_status(st->shard[s], d.stream));
+    nh[s] = total;
+    if (total == 0) return 0;
+    BIVX_TRY(grow(d.hits, (size_t)total * sizeof(uint32_t)));
+    uint32_t *dh = static_cast<uint32_t *>(d.hits.p);
+    BIVX_TRY(bivx_query_dev_s(st->shard[s], qchrom ? dq : nullptr, dq + m, dq + 2 * m, m, nullptr, sort_by_id, doff, dh, total,
+                              nullptr, 0, d.stream));
+    if (st->by_chrom) {  // (shard-local ids ascend with the global ones: an ordered list stays ordered)
+      const auto &gl = st->gid[s];
+      if (d.gid_n != gl.size() || !d.gid.p) {
+        BIVX_TRY(grow(d.gid, gl.size() * sizeof(uint32_t)));
+        BIVX_HIP(hipMemcpyAsync(d.gid.p, gl.data(), gl.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        d.gid_n = gl.size();
+      }
+      hipLaunchKernelGGL(k_map_ids, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d.stream, dh, total,
+                         static_cast<const uint32_t *>(d.gid.p));
+      BIVX_HIP(hipGetLastError());
+    }
+    BIVX_HIP(hipStreamSynchronize(d.stream));
+    return bivx_stream_status(st->shard[s], d.stream);
+  }));
+  // 2. sizes: ncclAllGather of (queries, ids) per device — every device learns every block's size, as a consumer on
+  // any device would need them; the host's copy of the same numbers drives the displacements below
+  const bool rccl = !st->comms.empty();
+  std::vector<uint64_t> qdisp(k + 1, 0), hdisp(k + 1, 0);
+  for (size_t s = 0; s < k; ++s) {
+    qdisp[s + 1] = qdisp[s] + nq[s];
+    hdisp[s + 1] = hdisp[s] + nh[s];
+  }
+  const uint64_t rows = qdisp[k], total = hdisp[k];
+  if (rccl) {
+    for (size_t s = 0; s < k; ++s) {
+      OnDevice g(st->devices[s]);
+      const uint64_t mine[2] = {nq[s], nh[s]};
+      BIVX_HIP(hipMemcpyAsync(st->dev[s].sizes.p, mine, sizeof(mine), hipMemcpyHostToDevice, st->dev[s].stream));
+      BIVX_HIP(hipStreamSynchronize(st->dev[s].stream));  // (`mine` is a stack array)
+    }
+    BIVX_NCCL(ncclGroupStart());
+    for (size_t s = 0; s < k; ++s) {
+      uint64_t *sz = static_cast<uint64_t *>(st->dev[s].sizes.p);
+      const ncclResult_t e = ncclAllGather(sz, sz + 2, 2, ncclUint64, st->comms[s], st->dev[s].stream);
+      if (e != ncclSuccess) {
+        (void)ncclGroupEnd();
+        set_error("ncclAllGather failed: %s", ncclGetErrorString(e));
+        return BIVX_E_COMM;
+      }
+    }
+    BIVX_NCCL(ncclGroupEnd());
+    std::vector<uint64_t> seen(2 * k);
+    {
+      OnDevice g(st->devices[0]);
+      BIVX_HIP(hipMemcpyAsync(seen.data(), static_cast<uint64_t *>(st->dev[0].sizes.p) + 2, 2 * k * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, st->dev[0].stream));
+      BIVX_HIP(hipStreamSynchronize(st->dev[0].stream));
+    }
+    for (size_t s = 0; s < k; ++s)
+      if (seen[2 * s] != nq[s] || seen[2 * s + 1] != nh[s]) {
+        set_error("bivx_query_sharded_dev: the gathered sizes of device %d are (%llu, %llu), expected (%llu, %llu)",
+                  st->devices[s], (unsigned long long)seen[2 * s], (unsigned long long)seen[2 * s + 1],
+                  (unsigned long long)nq[s], (unsigned long long)nh[s]);
+        return BIVX_E_COMM;
+      }
+  }
+  // 3. the blocks travel to devices[0]: offsets (without their last entry) and ids of every shard, each peer over its own
+  // link, all inside ONE group; the root's own block is a local copy
+  OnDevice root(st->devices[0]);
+  if (!root.ok) {
+    set_error("hipSetDevice(%d) failed", st->devices[0]);
+    return BIVX_E_HIP;
+  }
+  hipStream_t rs = st->dev[0].stream;
+  BIVX_TRY(grow(st->out_off, (rows + 1) * sizeof(uint64_t) + 2 * (k + 1) * sizeof(uint64_t)));
+  BIVX_TRY(grow(st->out_hits, std::max<uint64_t>(total, 1) * sizeof(uint32_t)));
+  BIVX_TRY(grow(st->out_rows, std::max<uint64_t>(rows, 1) * sizeof(uint32_t)));
+  uint64_t *o_off = static_cast<uint64_t *>(st->out_off.p);
+  uint32_t *o_hits = static_cast<uint32_t *>(st->out_hits.p);
+  uint64_t *o_disp = o_off + rows + 1;  // (qdisp | hdisp for the rebasing kernel, behind the offsets)
+  auto local_copy = [&](size_t s) -> int {
+    if (nq[s]) BIVX_HIP(hipMemcpyAsync(o_off + qdisp[s], st->dev[s].off.p, nq[s] * sizeof(uint64_t), hipMemcpyDeviceToDevice, rs));
+    if (nh[s]) BIVX_HIP(hipMemcpyAsync(o_hits + hdisp[s], st->dev[s].hits.p, nh[s] * sizeof(uint32_t), hipMemcpyDeviceToDevice, rs));
+    return 0;
+  };
+  BIVX_TRY(local_copy(0));
+  if (rccl && k > 1) {
+    BIVX_NCCL(ncclGroupStart());
+    ncclResult_t e = ncclSuccess;
+    for (size_t s = 1; s < k && e == ncclSuccess; ++s) {
+      if (nq[s]) e = ncclRecv(o_off + qdisp[s], nq[s], ncclUint64, (int)s, st->comms[0], rs);
+      if (e == ncclSuccess && nh[s]) e = ncclRecv(o_hits + hdisp[s], nh[s], ncclUint32, (int)s, st->comms[0], rs);
+      if (e == ncclSuccess && nq[s]) e = ncclSend(st->dev[s].off.p, nq[s], ncclUint64, 0, st->comms[s], st->dev[s].stream);
+      if (e == ncclSuccess && nh[s]) e = ncclSend(st->dev[s].hits.p, nh[s], ncclUint32, 0, st->comms[s], st->dev[s].stream);
+    }
+    if (e != ncclSuccess) {
+      (void)ncclGroupEnd();
+      set_error("ncclSend / ncclRecv failed: %s", ncclGetErrorString(e));
+      return BIVX_E_COMM;
+    }
+    BIVX_NCCL(ncclGroupEnd());
+  } else {
+    for (size_t s = 1; s < k; ++s) BIVX_TRY(local_copy(s));  // (shards that share the root's device: nothing to send)
+  }
+  // 4. offsets rebased to the gathered ids, the rows' batch indices
+  std::vector<uint64_t> disp(2 * (k + 1));
+  std::copy(qdisp.begin(), qdisp.end(), disp.begin());
+  std::copy(hdisp.begin(), hdisp.end(), disp.begin() + (k + 1));
+  BIVX_HIP(hipMemcpyAsync(o_disp, disp.data(), disp.size() * sizeof(uint64_t), hipMemcpyHostToDevice, rs));
+  hipLaunchKernelGGL(k_rebase_offsets, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, rs, o_off, o_disp, o_disp + (k + 1),
+                     (uint32_t)k, rows, total);
+  BIVX_HIP(hipGetLastError());
+  std::vector<uint32_t> row_q;
+  row_q.reserve(rows);
+  for (size_t s = 0; s < k; ++s) row_q.insert(row_q.end(), r.qs[s].begin(), r.qs[s].end());
+  if (rows) BIVX_HIP(hipMemcpyAsync(st->out_rows.p, row_q.data(), rows * sizeof(uint32_t), hipMemcpyHostToDevice, rs));
+  BIVX_HIP(hipStreamSynchronize(rs));
+  for (size_t s = 1; s < k; ++s) {  // the peers' sends are complete when their streams are
+    OnDevice g(st->devices[s]);
+    BIVX_HIP(hipStreamSynchronize(st->dev[s].stream));
+  }
+  out->d_offsets = o_off;
+  out->d_hit_ids = o_hits;
+  out->d_query_of_row = static_cast<uint32_t *>(st->out_rows.p);
+  out->rows = rows;
+  out->total = total;
+  out->device = st->devices[0];
+  out->used_rccl = rccl ? 1 : 0;
+  return 0;
+}
+
+static void release_dev_state(ShardedState *st) {
+  for (auto c : st->comms)
+    if (c) (void)ncclCommDestroy(c);
+  st->comms.clear();
+  for (size_t s = 0; s < st->dev.size(); ++s) {
+    OnDevice g(st->devices[s]);
+    ShardedState::ShardDev &d = st->dev[s];
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    for (ShardedState::Buf *b : {&d.q, &d.off, &d.hits, &d.gid, &d.sizes}) (void)hipFree(b->p);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+  }
+  st->dev.clear();
+  if (!st->devices.empty()) {
+    OnDevice g(st->devices[0]);
+    for (ShardedState::Buf *b : {&st->out_off, &st->out_hits, &st->out_rows}) {
+      (void)hipFree(b->p);
+      b->p = nullptr;
+      b->cap = 0;
+    }
+  }
+}
+
 void sharded_stats(const ShardedState *st, bivx_stats *out) {
   std::memset(out, 0, sizeof(*out));
   out->n_intervals = st->low.size();
@@ -504,6 +826,10 @@ int sharded_fill(const ShardedState *st, const uint32_t *qchrom, const uint32_t 
 int sharded_any(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
                 size_t q, uint32_t *first_id_out) {
   return no_throw("bivx_any", [&] { return any_impl(st, qchrom, qlow, qhigh, q, first_id_out); });
+}
+int sharded_query_dev(const ShardedState *st, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                      size_t q, int sort_by_id, bivx_sharded_result *out) {
+  return no_throw("bivx_query_sharded_dev", [&] { return query_dev_impl(st, qchrom, qlow, qhigh, q, sort_by_id, out); });
 }
 
 }  // namespace bivx

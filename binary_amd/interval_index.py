@@ -315,6 +315,34 @@ class IntervalIndex:
                                                   hits.numel(), s))
         return offsets, hits
 
+    def query_sharded_device(self, qlow, qhigh, qchrom=None, sort_by_id: bool = False):
+        """A sharded handle's batch with the result left on the device (bivx_query_sharded_dev): every device answers its
+        chromosomes, RCCL gathers the CSRs into devices[0]. Host arrays in; returns torch tensors on devices[0]
+        (offsets int64[rows + 1], hit ids int32[total] — global ids —, query_of_row int32[rows]) COPIED out of the handle's
+        buffers, and whether the blocks travelled through RCCL."""
+        qlow, qhigh = _u32(qlow), _u32(qhigh)
+        qchrom = _u32(qchrom) if qchrom is not None else None
+        res = capi.ShardedResult()
+        capi.check(self._L.bivx_query_sharded_dev(self._h, _ptr(qchrom), _ptr(qlow), _ptr(qhigh), qlow.size, int(sort_by_id),
+                                                  C.byref(res)))
+        dev = torch.device("cuda", res.device)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+        def take(ptr, n, dtype, itemsize):
+            t = torch.empty(n, dtype=dtype, device=dev)
+            if n:
+                with torch.cuda.device(dev):
+                    rc = hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), n * itemsize, 3)  # device to device
+                if rc != 0:
+                    raise RuntimeError(f"hipMemcpy of the gathered result failed: {rc}")
+            return t
+
+        off = take(res.d_offsets, res.rows + 1, torch.int64, 8)
+        hits = take(res.d_hit_ids, res.total, torch.int32, 4)
+        rows = take(res.d_query_of_row, res.rows, torch.int32, 4)
+        return off, hits, rows, bool(res.used_rccl)
+
     def find_overlaps_device(self, qlow, qhigh, qchrom=None, sort_by_id: bool = False):
         """(offsets int64[q+1], hits int32[H]) as device tensors. One host sync to size the hit buffer."""
         offsets = self.count_overlaps_device(qlow, qhigh, qchrom)

@@ -42,6 +42,7 @@ typedef enum bivx_status {
   BIVX_E_NOMEM = -3,   /* host allocation failed */
   BIVX_E_STATE = -4,   /* e.g. query before build */
   BIVX_E_RANGE = -5,   /* too many intervals (>= 2^32-1) or chromosome ids (> BIVX_MAX_CHROMS) */
+  BIVX_E_COMM = -7,    /* an RCCL call of bivx_query_sharded_dev failed (text in bivx_last_error) */
   BIVX_E_TIMEOUT = -6  /* a single-pass query kernel gave up a bounded cross-workgroup wait, or found its prefix
                           workspace in an inconsistent state: the CSR of that call is INVALID (never returned with
                           rc 0); the index stays usable, repeat the call */
@@ -51,7 +52,7 @@ typedef enum bivx_status {
 #define BIVX_NO_HIT 0xFFFFFFFFu
 
 /* ABI version of this header: major << 16 | minor. */
-#define BIVX_ABI_VERSION 0x00020002u
+#define BIVX_ABI_VERSION 0x00020003u
 uint32_t bivx_abi_version(void);
 const char *bivx_last_error(void);
 
@@ -81,6 +82,32 @@ void bivx_release_pooled(void);
 int bivx_create_sharded(bivx_index **out, const int *devices, int ndev);
 int bivx_num_devices(const bivx_index *idx);                     /* 1 for a bivx_create handle */
 int bivx_device_of_chrom(const bivx_index *idx, uint32_t chrom); /* after build; -1: no interval on that chromosome */
+
+/* The batch answered by a sharded handle with the result left ON THE DEVICE: the final gatherv of the per-chromosome hit
+ * lists (BASELINE north_star) below the C ABI.
+ * replaces: the reference's tasks handing their hit lists to one writer (mapper.hpp:238-246, mapper.cpp:127-142,
+ * writer.hpp:27-53) — here every device answers the queries of ITS chromosomes into its own device buffers
+ * (bivx_query_dev_s per shard, ids mapped to the handle's global append-order ids on the device), then the CSRs are
+ * gathered into devices[0]'s memory over RCCL: ncclCommInitAll over the handle's devices (once per handle),
+ * ncclAllGather of (queries, ids) per device, one ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd in which every
+ * peer's offsets and ids travel to device 0 over its own xGMI link, and a small kernel that rebases the offsets.
+ * Queries are HOST arrays (they are routed to their chromosome's device on the host, as for bivx_find_overlaps).
+ * Result (device memory of out->device, owned by the handle, valid until the next bivx_query_sharded_dev, bivx_build,
+ * bivx_clear or bivx_destroy on it): rows grouped by device — d_query_of_row[r] is the batch index of the query row r
+ * answers (with one device: 0, 1, 2, ...: the result is bivx_query_dev_s's CSR bit for bit); lists in index order, or
+ * ascending id with sort_by_id. A handle that names a device twice (tests on a one-GPU box) has no communicator — RCCL
+ * wants distinct devices — and moves the same blocks with device-to-device copies instead. A bivx_create handle
+ * gets BIVX_E_STATE (bivx_query_dev_s is its call). Every nccl* failure comes back as BIVX_E_COMM. */
+typedef struct bivx_sharded_result {
+  uint64_t *d_offsets;      /* u64[rows + 1] */
+  uint32_t *d_hit_ids;      /* u32[total], global (append-order) ids */
+  uint32_t *d_query_of_row; /* u32[rows] */
+  uint64_t rows, total;
+  int device;               /* the device that holds the three arrays: devices[0] */
+  int used_rccl;            /* 1: the blocks travelled through ncclSend / ncclRecv; 0: device-to-device copies */
+} bivx_sharded_result;
+int bivx_query_sharded_dev(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
+                           size_t q, int sort_by_id, bivx_sharded_result *out);
 
 /* ---- build side -------------------------------------------------------------------------------
  * replaces: RbTree::insert_node(range) rb_tree.hpp:111-117 and insert_node(Args&&...) :145-149 — appends n

@@ -33,7 +33,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.bivx_abi_version() == 0x00020002  # 2.1: + bivx_self_overlaps_dev; 2.2: + bivx_release_pooled
+    assert lib.bivx_abi_version() == 0x00020003  # 2.1: + bivx_self_overlaps_dev; 2.2: + bivx_release_pooled; 2.3: + bivx_query_sharded_dev
 
 
 def test_code_object_is_gfx950(lib, tmp_path):

@@ -94,3 +94,115 @@ def test_sv2nl_tool_on_a_sharded_index(tmp_path):
         got = sorted(open(out + "." + k).read().splitlines()[1:])
         exp = sorted(open(os.path.join(vcf, f"pair_expected.{k}.tsv")).read().splitlines()[1:])
         assert got == exp, k
+
+
+# ---- bivx_query_sharded_dev: the gathered device-resident CSR (RCCL gatherv below the C ABI) ---------------------------
+
+def _rows_as_lists(off, hits, rows, q):
+    """per batch query: its list of the gathered CSR (rows are grouped by device: query_of_row says whose row it is)"""
+    off, hits, rows = off.cpu().numpy(), hits.cpu().numpy().view(np.uint32), rows.cpu().numpy()
+    assert rows.size == q and np.array_equal(np.sort(rows), np.arange(q)), "every query has exactly one row"
+    out = [None] * q
+    for r, qi in enumerate(rows):
+        out[qi] = hits[off[r]:off[r + 1]]
+    return out
+
+
+@pytest.mark.parametrize("sort_by_id", [False, True])
+def test_sharded_dev_one_device_communicator_equals_the_single_index_bit_for_bit(sort_by_id):
+    """devices = [0]: ncclCommInitAll over one device, ncclAllGather of the sizes on a one-rank communicator; the root's
+    block is a local copy. The gathered CSR must be bivx_query_dev_s's, bit for bit."""
+    import torch
+    from binary_amd import IntervalIndex, synth
+    d = synth.gen_genome(400_000, 250_000, 1000)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(d["qlow"].size)
+    qc, qlo, qhi = d["qchrom"][perm], d["qlow"][perm], d["qhigh"][perm]
+    qc[:50] = 77                                   # queries on a chromosome nobody holds: empty rows
+    dev = torch.device("cuda:0")
+    to = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev)
+    with IntervalIndex(0) as one, IntervalIndex([0]) as sh:
+        for idx in (one, sh):
+            idx.insert_node(d["low"], d["high"], d["chrom"])
+            idx.build()
+        off1 = one.count_overlaps_device(to(qlo), to(qhi), to(qc))
+        hits1 = torch.empty(int(off1[-1].item()), dtype=torch.int32, device=dev)
+        one.query_device(to(qlo), to(qhi), off1, hits1, qchrom=to(qc), sort_by_id=sort_by_id)
+        off2, hits2, rows, used_rccl = sh.query_sharded_device(qlo, qhi, qc, sort_by_id=sort_by_id)
+        assert used_rccl, "one distinct device: the RCCL path (communicator of one rank)"
+        assert torch.equal(rows, torch.arange(qlo.size, dtype=torch.int32, device=dev))
+        assert torch.equal(off1, off2) and torch.equal(hits1, hits2)
+        # a second call reuses the handle's buffers and the communicator; a smaller batch, after a rebuild
+        sh.insert_node(d["low"][:1000], d["high"][:1000], d["chrom"][:1000])
+        sh.build()
+        one.insert_node(d["low"][:1000], d["high"][:1000], d["chrom"][:1000])
+        one.build()
+        off1 = one.count_overlaps_device(to(qlo[:9999]), to(qhi[:9999]), to(qc[:9999]))
+        hits1 = torch.empty(int(off1[-1].item()), dtype=torch.int32, device=dev)
+        one.query_device(to(qlo[:9999]), to(qhi[:9999]), off1, hits1, qchrom=to(qc[:9999]), sort_by_id=sort_by_id)
+        off2, hits2, rows, _ = sh.query_sharded_device(qlo[:9999], qhi[:9999], qc[:9999], sort_by_id=sort_by_id)
+        assert torch.equal(off1, off2) and torch.equal(hits1, hits2)
+
+
+@pytest.mark.parametrize("sort_by_id", [False, True])
+def test_sharded_dev_three_shards_same_lists_as_the_single_index(sort_by_id, oracle):
+    """devices = [0, 0, 0]: three shards on the one card — the routing, the per-shard device CSRs, the local -> global id
+    mapping on the device, the displacement arithmetic and the rebasing kernel of a three-device gather; the blocks move by
+    device-to-device copies because RCCL refuses a device twice in one communicator (used_rccl == False)."""
+    from binary_amd import IntervalIndex, synth
+    d = synth.gen_genome(300_000, 200_000, 1000)
+    rng = np.random.default_rng(4)
+    perm = rng.permutation(d["qlow"].size)
+    qc, qlo, qhi = d["qchrom"][perm], d["qlow"][perm], d["qhigh"][perm]
+    qc[::1000] = 31                                # no device holds chromosome 31
+    with IntervalIndex(0) as one, IntervalIndex([0, 0, 0]) as sh:
+        for idx in (one, sh):
+            idx.insert_node(d["low"], d["high"], d["chrom"])
+            idx.build()
+        off1, hits1 = one.find_overlaps(qlo, qhi, qc, sort_by_id=sort_by_id)
+        off2, hits2, rows, used_rccl = sh.query_sharded_device(qlo, qhi, qc, sort_by_id=sort_by_id)
+        assert not used_rccl
+        assert int(off2[-1].item()) == int(off1[-1]) == hits2.numel()
+        lists = _rows_as_lists(off2, hits2, rows, qlo.size)
+        for qi in range(qlo.size):
+            a = hits1[int(off1[qi]):int(off1[qi + 1])]
+            # (index order of a shard is index order of the single index restricted to its chromosomes, in global ids only
+            # after sorting: compare as sets unless ascending ids were asked for)
+            b = lists[qi]
+            assert np.array_equal(a, b) if sort_by_id else np.array_equal(np.sort(a), np.sort(b)), qi
+        # rows are grouped by device, in batch order inside a group
+        r = rows.cpu().numpy()
+        devs = np.array([0 if c >= 24 else sh.device_of_chrom(int(c)) for c in qc])
+        assert (devs == 0).all()                   # (one card)
+        # a replicated handle (one populated chromosome, three shards): the queries are split instead
+        sel = d["chrom"] == 0
+        with IntervalIndex([0, 0, 0]) as rep, IntervalIndex(0) as one0:
+            for idx in (rep, one0):
+                idx.insert_node(d["low"][sel], d["high"][sel])
+                idx.build()
+            q0 = d["qchrom"] == 0
+            o1, h1 = one0.find_overlaps(d["qlow"][q0], d["qhigh"][q0], sort_by_id=True)
+            o2, h2, rows2, _ = rep.query_sharded_device(d["qlow"][q0], d["qhigh"][q0], sort_by_id=True)
+            assert np.array_equal(rows2.cpu().numpy(), np.arange(int(q0.sum())))
+            assert np.array_equal(o2.cpu().numpy().astype(np.uint64), o1) and np.array_equal(h2.cpu().numpy().view(np.uint32), h1)
+
+
+def test_sharded_dev_rejects_a_plain_handle_and_an_unbuilt_one():
+    from binary_amd import IntervalIndex, capi
+    q = np.array([5], np.uint32)
+    with IntervalIndex(0) as one:
+        one.insert_node(q, q)
+        one.build()
+        with pytest.raises(capi.BivxError) as e:
+            one.query_sharded_device(q, q)
+        assert e.value.code == capi.E_STATE
+    with IntervalIndex([0]) as sh:
+        sh.insert_node(q, q)
+        with pytest.raises(capi.BivxError) as e:
+            sh.query_sharded_device(q, q)
+        assert e.value.code == capi.E_STATE
+        sh.build()
+        off, hits, rows, _ = sh.query_sharded_device(q, q)
+        assert off.tolist() == [0, 1] and hits.tolist() == [0] and rows.tolist() == [0]
+        off, hits, rows, _ = sh.query_sharded_device(q[:0], q[:0])
+        assert off.tolist() == [0] and hits.numel() == 0 and rows.numel() == 0
