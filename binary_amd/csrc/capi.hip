@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -107,11 +108,21 @@ struct bivx_index {
   // bivx_find_overlaps: the kernel reads the queries and writes offsets and ids straight through them
   mutable std::vector<std::pair<void *, void *>> mailboxes;
   mutable size_t cache_bytes = 0;
-  // The host-pointer query entry points all launch on idx->stream and share ONE error block: held from a call's first
-  // launch to its report, so that a thread's synchronisation cannot cover — and its report consume — another thread's
-  // failed kernel (sv2nl runs three mappers on one index). The device work of such calls is serialised by the shared
-  // stream anyway.
-  mutable std::mutex call_mutex;
+  // Const queries on one index from several host threads (the reference shares one tree across its pool threads,
+  // mapper.cpp:127-142): every host-pointer query call runs on a LANE of its own — a stream, an error block (pinned, mapped
+  // into the device) and, through ws_of_stream, a prefix workspace — so that the calls' device round trips overlap and a
+  // failed kernel is reported to the call that launched it. Lane 0 is (idx->stream, h_err, d_err); further lanes are made
+  // when a call finds none free, up to kMaxLanes (beyond that a call waits for one).
+  struct Lane {
+    hipStream_t stream = nullptr;
+    uint32_t *h_err = nullptr, *d_err = nullptr;
+  };
+  static constexpr size_t kMaxLanes = 32;
+  mutable std::mutex lane_mutex;
+  mutable std::condition_variable lane_cv;
+  mutable std::vector<Lane> lanes_free;
+  mutable size_t lanes_made = 0;  // lane 0 included once it has been handed out for the first time
+  mutable std::vector<Lane> lanes_all;  // (for teardown)
 };
 
 // the device-pointer entry points address ONE device's memory: a sharded handle has no meaning for them
@@ -168,14 +179,15 @@ hipError_t dev_malloc(void **p, size_t bytes) {
 struct TempPool {
   static constexpr size_t kMaxCachedBlock = 16u << 20, kMaxCachedTotal = 256u << 20;
   const bivx_index *idx;
+  hipStream_t stream;  // the stream the call's work runs on (its lane's)
   std::vector<std::pair<void *, size_t>> ptrs;
-  explicit TempPool(const bivx_index *owner) : idx(owner) {}
+  explicit TempPool(const bivx_index *owner, hipStream_t s = nullptr) : idx(owner), stream(s ? s : (owner ? owner->stream : nullptr)) {}
   TempPool(const TempPool &) = delete;
   TempPool &operator=(const TempPool &) = delete;
   ~TempPool() {
-    // every user has synchronised idx->stream on its way out; an error return may not have, and a recycled block
+    // every user has synchronised its stream on its way out; an error return may not have, and a recycled block
     // must not be in use: an idle stream makes this a no-op
-    if (idx && idx->stream && !ptrs.empty()) (void)hipStreamSynchronize(idx->stream);
+    if (idx && stream && !ptrs.empty()) (void)hipStreamSynchronize(stream);
     for (auto &b : ptrs) {
       if (!b.first) continue;
       if (idx && b.second <= kMaxCachedBlock) {
@@ -538,6 +550,9 @@ int bits_for(uint32_t maxval) {
   return b;
 }
 
+// the error block the calling thread's kernels report to: its lane's, inside a host-pointer query call (LaneLease)
+static thread_local uint32_t *g_lane_d_err = nullptr;
+
 IndexView view_of(const bivx_index *idx, uint32_t svtype = 0) {
   IndexView v;
   v.se = idx->d_se;
@@ -559,15 +574,15 @@ IndexView view_of(const bivx_index *idx, uint32_t svtype = 0) {
   v.flt_strand = 0;
   v.flt_qaux = nullptr;
   v.flt_iaux = nullptr;
-  v.err = idx->d_err;
+  v.err = g_lane_d_err ? g_lane_d_err : idx->d_err;
   return v;
 }
 
 // Turns a raised error word into BIVX_E_TIMEOUT, once. Call after a synchronisation that covers the kernels in
 // question. The words are reset and every index-owned workspace is cleared before its next launch.
-int report_device_errors(const bivx_index *idx, const char *who) {
+int report_device_errors(const bivx_index *idx, const char *who, uint32_t *block = nullptr) {
   // read-and-clear in one step per word: a flag the device raises between a read and a separate clear would be lost
-  uint32_t *e = idx->h_err;
+  uint32_t *e = block ? block : idx->h_err;
   if (__atomic_load_n(&e[kErrTimeout], __ATOMIC_RELAXED) == 0 && __atomic_load_n(&e[kErrWorkspace], __ATOMIC_RELAXED) == 0)
     return 0;
   const bool timeout = __atomic_exchange_n(&e[kErrTimeout], 0u, __ATOMIC_ACQ_REL) != 0;
@@ -584,6 +599,67 @@ int report_device_errors(const bivx_index *idx, const char *who) {
             dirty ? "a single-pass query kernel found its prefix workspace not zeroed" : "");
   return BIVX_E_TIMEOUT;
 }
+
+// A host-pointer query call's lane for its duration (bivx_index::Lane). While it is held the calling thread's kernels
+// report to the lane's error block (view_of) and report() reads that block.
+struct LaneLease {
+  const bivx_index *idx;
+  bivx_index::Lane lane;
+  bool ok = false;
+  explicit LaneLease(const bivx_index *owner) : idx(owner) {
+    std::unique_lock<std::mutex> lock(idx->lane_mutex);
+    for (;;) {
+      if (!idx->lanes_free.empty()) {
+        lane = idx->lanes_free.back();
+        idx->lanes_free.pop_back();
+        ok = true;
+        break;
+      }
+      if (idx->lanes_made == 0) {  // lane 0: what a single-threaded caller has always run on
+        lane.stream = idx->stream;
+        lane.h_err = idx->h_err;
+        lane.d_err = idx->d_err;
+        idx->lanes_made = 1;
+        ok = true;
+        break;
+      }
+      if (idx->lanes_made < bivx_index::kMaxLanes) {
+        bivx_index::Lane l;
+        void *h = nullptr, *d = nullptr;
+        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipHostMalloc(&h, kErrWords * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+          std::memset(h, 0, kErrWords * sizeof(uint32_t));
+          l.h_err = static_cast<uint32_t *>(h);
+          l.d_err = static_cast<uint32_t *>(d);
+          idx->lanes_all.push_back(l);
+          ++idx->lanes_made;
+          lane = l;
+          ok = true;
+          break;
+        }
+        (void)hipGetLastError();
+        if (h) (void)hipHostFree(h);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+        // (no more to be had: wait for one like everybody beyond kMaxLanes)
+      }
+      idx->lane_cv.wait(lock);
+    }
+    if (ok) g_lane_d_err = lane.d_err;
+  }
+  ~LaneLease() {
+    g_lane_d_err = nullptr;
+    if (!ok) return;
+    {
+      std::lock_guard<std::mutex> lock(idx->lane_mutex);
+      idx->lanes_free.push_back(lane);
+    }
+    idx->lane_cv.notify_one();
+  }
+  int report(const char *who) const { return report_device_errors(idx, who, lane.h_err); }
+  LaneLease(const LaneLease &) = delete;
+  LaneLease &operator=(const LaneLease &) = delete;
+};
 
 // view with a fused post-filter; the aux pointers are DEVICE pointers here
 int view_with_filter(const bivx_index *idx, const bivx_filter *f, IndexView &v) {
@@ -665,6 +741,10 @@ void destroy_now(bivx_index *idx) {
     (void)hipFree(kv.second.self_p);
   }
   if (idx->h_err) (void)hipHostFree(idx->h_err);
+  for (auto &l : idx->lanes_all) {  // (lane 0 is idx->stream / h_err themselves and not in this list)
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+    if (l.h_err) (void)hipHostFree(l.h_err);
+  }
   for (auto &m : idx->mailboxes) (void)hipHostFree(m.first);
   idx->mailboxes.clear();
   drop_block_cache(idx);
@@ -1473,18 +1553,18 @@ struct Mailbox {
 // A handful of queries (the facade's per-record calls, interval_tree.hpp:306-334 under mapper.hpp:218): no copies at all.
 // The queries are written into a mailbox, the single-pass kernel reads them and writes offsets and ids through the
 // same mapping, and the stream is synchronised once. Returns kSmallBatchOverflow if the ids did not fit.
-int find_overlaps_tiny(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
-                       size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+int find_overlaps_tiny(const bivx_index *idx, const LaneLease &lease, const uint32_t *qchrom, const uint32_t *qlow,
+                       const uint32_t *qhigh, size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
                        uint32_t **hit_ids_out);
 
-int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
-                        size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+int find_overlaps_small(const bivx_index *idx, const LaneLease &lease, const uint32_t *qchrom, const uint32_t *qlow,
+                        const uint32_t *qhigh, size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
                         uint32_t **hit_ids_out) {
-  hipStream_t s = idx->stream;
+  hipStream_t s = lease.lane.stream;
   const size_t nq_words = (qchrom ? 3 : 2) * q;
   const size_t cap = kSmallBatchIds * q + 1024;
   const size_t off_words = 2 * (q + 1);                     // u64 offsets, as u32 words
-  TempPool tmp(idx);
+  TempPool tmp(idx, s);
   uint32_t *d_buf = nullptr;                               // [queries | pad to 8 B | offsets | ids]
   const size_t q_words = (nq_words + 1) & ~size_t(1);
   BIVX_TRY(tmp.alloc(&d_buf, q_words + off_words + cap));
@@ -1502,7 +1582,7 @@ int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uin
   const size_t have = std::min(cap, 4 * q + 128);
   BIVX_HIP(hipMemcpyAsync(h.data(), d_off, (off_words + have) * 4, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
-  BIVX_TRY(report_device_errors(idx, "bivx_find_overlaps"));
+  BIVX_TRY(lease.report("bivx_find_overlaps"));
   const uint64_t *off = reinterpret_cast<const uint64_t *>(h.data());
   const uint64_t total = off[q];
   if (total > cap) return kSmallBatchOverflow;
@@ -1515,7 +1595,8 @@ int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uin
   }
   if (total <= have) {
     std::memcpy(out, h.data() + off_words, (size_t)total * 4);
-  } else if (hipMemcpy(out, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+  } else if (hipMemcpyAsync(out, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+             hipStreamSynchronize(s) != hipSuccess) {
     std::free(out);
     set_error("bivx_find_overlaps: device copy failed");
     return BIVX_E_HIP;
@@ -1524,12 +1605,12 @@ int find_overlaps_small(const bivx_index *idx, const uint32_t *qchrom, const uin
   return 0;
 }
 
-int find_overlaps_tiny(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
-                       size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
+int find_overlaps_tiny(const bivx_index *idx, const LaneLease &lease, const uint32_t *qchrom, const uint32_t *qlow,
+                       const uint32_t *qhigh, size_t q, const bivx_filter *filter, int sort_by_id, uint64_t *offsets_out,
                        uint32_t **hit_ids_out) {
   Mailbox mb(idx);
   if (!mb.host) return kSmallBatchOverflow;  // (no mapping to be had: the copying path)
-  hipStream_t s = idx->stream;
+  hipStream_t s = lease.lane.stream;
   // layout (u32 words): [qlow | qhigh | qchrom] (3 x 64) [pad] [offsets: 65 x u64] [ids ...]
   const size_t q_words = 3 * kMailboxQueries, off_words = 2 * (kMailboxQueries + 1);
   const size_t cap = kMailboxBytes / 4 - q_words - off_words;
@@ -1547,7 +1628,7 @@ int find_overlaps_tiny(const bivx_index *idx, const uint32_t *qchrom, const uint
                         d + q_words + off_words, cap, s) != 0)
     return kSmallBatchOverflow;
   BIVX_HIP(hipStreamSynchronize(s));
-  BIVX_TRY(report_device_errors(idx, "bivx_find_overlaps"));
+  BIVX_TRY(lease.report("bivx_find_overlaps"));
   const uint64_t total = h_off[q];
   if (total > cap) return kSmallBatchOverflow;
   std::memcpy(offsets_out, h_off, (q + 1) * 8);
@@ -1612,9 +1693,9 @@ int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *
     return 0;
   }
   BIVX_GUARD(idx);
-  std::lock_guard<std::mutex> call_lock(idx->call_mutex);  // launch .. report, one call at a time (bivx_index::call_mutex)
-  hipStream_t s = idx->stream;
-  TempPool tmp(idx);
+  LaneLease lease(idx);  // launch .. report on a lane of this call's own (bivx_index::Lane)
+  hipStream_t s = lease.lane.stream;
+  TempPool tmp(idx, s);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
   uint64_t *d_off = nullptr;
@@ -1624,7 +1705,7 @@ int bivx_count_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *
   BIVX_TRY(bivx_count_dev_f(idx, d.c, d.lo, d.hi, q, &dflt, d_off, s));
   BIVX_HIP(hipMemcpyAsync(offsets_out, d_off, (q + 1) * 8, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
-  return report_device_errors(idx, "bivx_count");
+  return lease.report("bivx_count");
 }
 
 int bivx_fill(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh, size_t q,
@@ -1653,9 +1734,9 @@ int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *q
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
-  std::lock_guard<std::mutex> call_lock(idx->call_mutex);  // launch .. report, one call at a time (bivx_index::call_mutex)
-  hipStream_t s = idx->stream;
-  TempPool tmp(idx);
+  LaneLease lease(idx);  // launch .. report on a lane of this call's own (bivx_index::Lane)
+  hipStream_t s = lease.lane.stream;
+  TempPool tmp(idx, s);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
   uint64_t *d_off = nullptr;
@@ -1669,7 +1750,7 @@ int bivx_fill_f(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *q
   if (sort_by_id) BIVX_TRY(launch_sort_hits(d_off, d_hits, q, ~0ull, s, nullptr, 0, total ? total : 1));
   if (total) BIVX_HIP(hipMemcpyAsync(hit_ids_out, d_hits, (size_t)total * 4, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
-  return report_device_errors(idx, "bivx_fill");
+  return lease.report("bivx_fill");
 }
 
 int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow, const uint32_t *qhigh,
@@ -1693,16 +1774,17 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
     return 0;
   }
   BIVX_GUARD(idx);
-  std::lock_guard<std::mutex> call_lock(idx->call_mutex);  // launch .. report, one call at a time (bivx_index::call_mutex)
-  hipStream_t s = idx->stream;
+  LaneLease lease(idx);  // launch .. report on a lane of this call's own (bivx_index::Lane)
+  hipStream_t s = lease.lane.stream;
   if (q <= kSmallBatch && (!filter || filter->kind == BIVX_FILTER_NONE)) {
     int rc = kSmallBatchOverflow;
-    if (q <= kMailboxQueries) rc = find_overlaps_tiny(idx, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
+    if (q <= kMailboxQueries)
+      rc = find_overlaps_tiny(idx, lease, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
     if (rc == kSmallBatchOverflow)
-      rc = find_overlaps_small(idx, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
+      rc = find_overlaps_small(idx, lease, qchrom, qlow, qhigh, q, filter, sort_by_id, offsets_out, hit_ids_out);
     if (rc != kSmallBatchOverflow) return rc;
   }
-  TempPool tmp(idx);
+  TempPool tmp(idx, s);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
   bivx_filter dflt;
@@ -1714,7 +1796,7 @@ int bivx_find_overlaps(const bivx_index *idx, const uint32_t *qchrom, const uint
   BIVX_HIP(hipMemcpyAsync(&total, d_off + q, 8, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipMemcpyAsync(offsets_out, d_off, (q + 1) * 8, hipMemcpyDeviceToHost, s));
   BIVX_HIP(hipStreamSynchronize(s));
-  BIVX_TRY(report_device_errors(idx, "bivx_find_overlaps"));
+  BIVX_TRY(lease.report("bivx_find_overlaps"));
   if (total == 0) return 0;
   uint32_t *h = static_cast<uint32_t *>(std::malloc((size_t)total * sizeof(uint32_t)));
   if (!h) {
@@ -1754,7 +1836,8 @@ int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow
     return BIVX_E_INVALID;
   }
   BIVX_GUARD(idx);
-  hipStream_t s = idx->stream;
+  LaneLease lease(idx);
+  hipStream_t s = lease.lane.stream;
   if (q <= kMailboxQueries) {  // a handful of queries (the facade's find_overlap per record): through a mailbox, no copies
     Mailbox mb(idx);
     if (mb.host) {
@@ -1769,7 +1852,7 @@ int bivx_any(const bivx_index *idx, const uint32_t *qchrom, const uint32_t *qlow
       return 0;
     }
   }
-  TempPool tmp(idx);
+  TempPool tmp(idx, s);
   DevQueries d;
   BIVX_TRY(upload_queries(tmp, qchrom, qlow, qhigh, q, s, d));
   uint32_t *d_first = nullptr;
