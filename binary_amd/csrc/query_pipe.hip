@@ -73,8 +73,17 @@ constexpr unsigned kPStampTiles = 1024, kPStampSlots = 8;
 __device__ unsigned long long g_pstamps[kPStampTiles * kPStampSlots];
 #define PSTAMP(t, k) \
   if (threadIdx.x == 0) g_pstamps[((t) % kPStampTiles) * kPStampSlots + (k)] = __builtin_amdgcn_s_memrealtime()
+// ... and of the workgroup's life (k_query_pipe): 0 entry, 1 descriptors staged, 2 first ticket seen, 3 first queries and
+// probe issued, 4 worker 0 leaves (its last slice is out), 5 the service wavefront leaves, 6 tiles the workgroup drew
+__device__ unsigned long long g_wgstamps[1024 * 8];
+#define WGSTAMP(k) \
+  if ((threadIdx.x & 63u) == 0 && blockIdx.x < 1024) g_wgstamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#define WGSTAMP_VAL(k, v) \
+  if ((threadIdx.x & 63u) == 0 && blockIdx.x < 1024) g_wgstamps[blockIdx.x * 8 + (k)] = (v)
 #else
 #define PSTAMP(t, k)
+#define WGSTAMP(k)
+#define WGSTAMP_VAL(k, v)
 #endif
 
 struct PipeArgs {
@@ -395,6 +404,7 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
   uint32_t drawn = 0, published = 0, grouped = 0, swept = 0;
   uint32_t last_tile = 0;   // ticket of the newest drawn tile
   bool drawing = true;      // no ticket beyond the batch yet
+  bool first_round_over = false;  // every tile of the sharded first round is known to be drawn (see the ticket below)
   uint64_t stuck_since = 0; // when the oldest unswept tile's sweep was first found blocked
   const bool flat = pc.ntiles <= kFlatTiles;
   for (;;) {
@@ -410,19 +420,71 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
       TileSlot &sl = s_slot[drawn % kRing];
       // (the slot's last user was iteration drawn - kRing: swept, but every worker must also be through with it)
       if (want && (drawn < kRing || lds_load(&sl.flushed) == (uint32_t)NW)) {
-        uint32_t tile = 0;
+        // The ticket. The launch's first gridDim.x tiles are handed out by eight sharded counters (prefix_device.h,
+        // kTicketShards): a workgroup's FIRST draw takes from shard blockIdx % 8 without looking — the burst of first
+        // draws is what one counter word cannot take. Every later draw first makes sure that no first-round tile is left
+        // (a workgroup that was dispatched late, or not yet, has not drawn its own: somebody resident must, or the sweeps
+        // behind it would wait for a tile nobody holds) — a fresh look at the eight counters, usually one — and then takes
+        // from the single counter as before, which starts behind the first round.
+        uint64_t *const wsp = A(ws);
+        unsigned int *const tk = reinterpret_cast<unsigned int *>(wsp + kWsTickets);
+        auto shard_tiles = [&](uint32_t k) { return (gridDim.x + kTicketShards - 1 - k) / kTicketShards; };  // tiles of shard k
+        uint32_t tile = 0xFFFFFFFFu;
+        bool got = false;
+        if (drawn == 0) {
+          const uint32_t k = blockIdx.x & (kTicketShards - 1);
+          uint32_t c = 0;
+          if (lane == 0) c = atomicAdd(tk + k * (kTicketStride * 2), 1u);
+          c = __builtin_amdgcn_readfirstlane(c);
+          if (c < shard_tiles(k)) {
+            tile = c * kTicketShards + k;
+            got = true;
+          } else if (c > shard_tiles(k) + 2u * gridDim.x) {
+            // A shard is legitimately overshot — a workgroup that was dispatched late finds its first-round tile taken by
+            // one that came before it — but by no more than a draw or two per workgroup: beyond that the counters were not
+            // zero when the launch began (a launch that died half-way, a caller workspace that was not cleared) and
+            // nothing this launch writes can be trusted. Say so; the workgroup leaves at once (tile 0xFFFFFFFF).
+            if (lane == 0) raise_error(pc.err, kErrWorkspace);
+            got = true;
+          }
+        }
+        while (!got && !first_round_over) {
+          // fresh values (a returning atomic: a plain load may be served from this XCD's L2)
+          uint32_t next = 0xFFFFFFFFu;
+          if (lane < (int)kTicketShards) {
+            const uint32_t c = atomicAdd(tk + lane * (kTicketStride * 2), 0u);
+            if (c < shard_tiles((uint32_t)lane)) next = c * kTicketShards + (uint32_t)lane;
+          }
+          const uint32_t m = wave_min(next);
+          if (m == 0xFFFFFFFFu) {
+            first_round_over = true;
+            break;
+          }
+          const uint32_t k = m & (kTicketShards - 1);
+          uint32_t c = 0;
+          if (lane == 0) c = atomicAdd(tk + k * (kTicketStride * 2), 1u);
+          c = __builtin_amdgcn_readfirstlane(c);
+          if (c < shard_tiles(k)) {
+            tile = c * kTicketShards + k;
+            got = true;
+          }
+        }
+        if (!got) {
+          uint32_t t = 0;
+          if (lane == 0) t = atomicAdd(reinterpret_cast<unsigned int *>(wsp + kWsTicket), 1u);
+          tile = gridDim.x + __builtin_amdgcn_readfirstlane(t);
+          // Every workgroup draws exactly one ticket beyond the batch, so none can reach ntiles + gridDim.x unless the
+          // counter was not zero when the launch began: then tiles were skipped and nothing this launch wrote can be
+          // trusted. Say so.
+          if (tile >= pc.ntiles + gridDim.x && lane == 0) raise_error(pc.err, kErrWorkspace);
+        }
         if (lane == 0) {
-          tile = atomicAdd(reinterpret_cast<unsigned int *>(A(ws) + kWsTicket), 1u);
           sl.arrived = 0;
           sl.flushed = 0;
           sl.tile = tile;
           lds_store(&sl.gen_ticket, drawn + 1);
         }
-        last_tile = __builtin_amdgcn_readfirstlane(tile);
-        // Every workgroup draws exactly one ticket beyond the batch, so none can reach ntiles + gridDim.x unless
-        // the counter was not zero when the launch began (a launch that died half-way, a caller workspace that was
-        // not cleared): then tiles were skipped and nothing this launch wrote can be trusted. Say so.
-        if (last_tile >= pc.ntiles + gridDim.x && lane == 0) raise_error(pc.err, kErrWorkspace);
+        last_tile = tile;
         if (last_tile >= pc.ntiles) drawing = false;  // the workers see it, flush what is pending and leave
         ++drawn;
         progress = true;
@@ -506,6 +568,7 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
         pc.status[t] = 0;
         if (t < (pc.ntiles + kWave - 1) / kWave) pc.group[t] = 0;
       }
+      if (lane < (int)kTicketShards) ws[kWsTickets + (uint32_t)lane * kTicketStride] = 0;
       if (lane == 0) {
         ws[kWsTicket] = 0;
         ws[kWsDone] = 0;
@@ -520,6 +583,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
   (void)v_in;
   (void)a_in;
   kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+  if (threadIdx.x == 0) { WGSTAMP(0); }
   __shared__ SegDesc s_seg[kLdsSegs];
   __shared__ uint2 s_cs[kLdsChroms];
   __shared__ TileSlot s_slot[kRing];
@@ -544,11 +608,13 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     }
   }
   __syncthreads();  // the only barrier of the kernel
+  if (threadIdx.x == 0) { WGSTAMP(1); }
   const SegDesc *const segs = s_seg;
   const uint2 *const cs = s_cs;
 
   if (wave == kWorkers) {
     pipe_service_wave<kWorkers>(ka, s_slot, lane);
+    WGSTAMP(5);
     return;
   }
 
@@ -658,6 +724,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
   };
 
   lds_wait_eq(&s_slot[0].gen_ticket, 1u);
+  if (threadIdx.x == 0) { WGSTAMP(2); }
   uint32_t tile = __builtin_amdgcn_readfirstlane(s_slot[0].tile);
   // What a lane carries from one iteration to the next: its query of the coming tile and that query's directory
   // probe, both issued an iteration ahead (the queries when the ticket comes in, the probe when they have arrived —
@@ -670,6 +737,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
     qhi = q0.hi;
     wn = window_of(q0);
   }
+  if (threadIdx.x == 0) { WGSTAMP(3); }
 
   for (uint32_t it = 0;; ++it) {
     const bool live = tile < A(ntiles);
@@ -781,6 +849,10 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
 #pragma unroll
       for (uint32_t k = kDefer - 1; k-- > 0;)
         if (pd_[k].have) flush(pd_[k], it - 1 - k);
+      if (threadIdx.x == 0) {
+        WGSTAMP(4);
+        WGSTAMP_VAL(6, (unsigned long long)it);
+      }
       break;
     }
     PSTAMP(tile, 3);
@@ -2080,6 +2152,10 @@ int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const
 }
 
 #ifdef BIVX_STAMPS
+extern "C" int bivx_debug_wgstamps(unsigned long long *out, size_t n) {
+  if (n > 1024 * 8) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgstamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 extern "C" int bivx_debug_pstamps(unsigned long long *out, size_t n) {
   if (n > (size_t)kPStampTiles * kPStampSlots) n = (size_t)kPStampTiles * kPStampSlots;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
