@@ -55,7 +55,7 @@ constexpr uint32_t kRing = 8;                  // tile slots in LDS
 #define BIVX_COOP_DEPTH 2   // rounds of coop_mask32 whose loads are in flight together (1: load, wait, evaluate; 2 fits 64 registers)
 #endif
 #ifndef BIVX_EXP
-#define BIVX_EXP 0      // experiments (WRONG RESULTS, timing and instruction counts only): 1 no id layout, 2 no id stream-out, 4 no keep slots
+#define BIVX_EXP 0      // experiments (1, 2, 4: WRONG RESULTS, timing and instruction counts only): 1 no id layout, 2 no id stream-out, 4 no keep slots; 8: coop_mask32 instead of coop_place16 (same results)
 #endif
 constexpr uint32_t kDefer = BIVX_DEFER;  // iterations between counting a slice and writing it out (experiments: 1, 3)
 static_assert(kDefer >= 1 && kDefer <= 3, "deferral depth");
@@ -374,6 +374,105 @@ __device__ __forceinline__ uint32_t coop_mask32(const uint2 *rec, uint32_t *keep
 #undef BIVX_COOP_LOAD
 #undef BIVX_COOP_EVAL
   return m;
+}
+
+
+// ---- scattered windows of at most sixteen slots: the ids placed where they will leave from (round 4) ------------------
+// The rounds of coop_mask32 with the ROUND'S OWNERS NEIGHBOURS IN THE OUTPUT: in round k group g (lanes 8g .. 8g+7) fetches
+// the window of lane 8k + g (its words come through ds_bpermute), so the hits of a round are the lists of queries 8k .. 8k+7
+// back to back — in lane order, a lane's first record before its second, which IS slot order — and a hit's place in the
+// slice is (hits of the rounds before) + (hits of the lower lanes in this round): two v_mbcnt pairs on the round's two hit
+// masks. The lanes store their ids there at once (EXEC = the hit mask, no branch), into `out` — the wavefront's keep
+// region, which a straight copy moves to the output stage when that is free — and lane 8g leaves the group's first place
+// in `pos[8k + g]`: a query's offset in the slice; its count is the next query's offset minus its own. No per-owner hit
+// mask, no keep-slot ranking, no prefix sum, no per-lane layout loop: coop_mask32 + scan + layout were ~330 of the ~690
+// vector instructions of a slice, this is ~190 (profiles/r04_query_kernel_experiments.txt).
+// A group must know which of its sixteen records are the window's: the owner's word carries the number of slots n from
+// the even slot al on (0 .. 16) and whether a is odd — record A of lane p is the window's if (a odd ? p > 0 : true) and
+// 2p < n, record B if 2p + 1 < n. Wavefronts with a longer window, or a query whose low end lies more than 65535 above
+// its window's base (low > high queries), take coop_mask32.
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+// LDS store by the lanes of `mask` only (the mask becomes EXEC for the one instruction)
+__device__ __forceinline__ void lds_store_lanes(uint64_t mask, uint32_t byte_addr, uint32_t data) {
+  uint64_t saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved)
+               : "s"(mask), "v"(byte_addr), "v"(data)
+               : "memory");
+}
+
+constexpr uint32_t kPlacePos = 432;  // words of the keep region where the 65 offsets of a slice live (behind its <= kPStage ids)
+static_assert(kPStage <= kPlacePos && kPlacePos + 65u <= kWave * kPKeep, "the keep region holds a slice's ids and offsets");
+
+// Returns the slice's number of ids; `cnt` / `loff` receive the lane's own count and offset. `out`: the wavefront's keep
+// region (ids of the first kPStage places are stored, none if !store_ids).
+__device__ __forceinline__ uint32_t coop_place16(const uint2 *rec, uint32_t *out, const Win &w, bool nonempty, uint32_t lo,
+                                                 uint32_t hi, uint32_t lane, bool store_ids, uint32_t &cnt, uint32_t &loff) {
+  const uint32_t al = w.a & ~1u;
+  const uint32_t n = nonempty ? w.b - al : 0u;  // <= 16
+  uint32_t qh = hi - w.base, ql = lo > w.base ? lo - w.base : 0u;  // (ql <= 0xFFFF: the caller has looked)
+  qh = qh > 0xFFFFu ? 0xFFFFu : qh;
+  const uint32_t w0 = (al >> 1) | n << 26 | (nonempty ? (w.a & 1u) : 0u) << 31;
+  const uint32_t w2 = ql | qh << 16;
+  const char *rb = reinterpret_cast<const char *>(rec);
+  const uint32_t p = lane & 7u, p2 = 2u * p, p2p1 = 2u * p + 1u;
+  const uint32_t from = (lane >> 3) << 2;                 // ds_bpermute address of lane (lane >> 3); + 32 k: lane 8k + (lane >> 3)
+  const uint32_t out_addr = lds_addr_of(out);
+  const uint32_t pos_addr = out_addr + (kPlacePos << 2) + from;   // + 32 k: word 8k + (lane >> 3)
+  constexpr uint64_t kP0 = 0x0101010101010101ull;         // the groups' first lanes
+  uint32_t wpos = 0;                                      // hits of the rounds so far (wavefront-uniform)
+
+#define BIVX_PLACE_LOAD(k)                                                                                            \
+  const uint32_t s0_##k = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from + 32u * (k)), (int)w0);                   \
+  const uint32_t s1_##k = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from + 32u * (k)), (int)w.base);              \
+  const uint32_t s2_##k = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from + 32u * (k)), (int)w2);                  \
+  const uint32_t n_##k = (s0_##k >> 26) & 31u;                                                                        \
+  const uint64_t inA_##k = __builtin_amdgcn_uicmp(p2, n_##k, 36), inB_##k = __builtin_amdgcn_uicmp(p2p1, n_##k, 36);  \
+  /* (a odd: the group's first record is the slot before the window) */                                               \
+  const uint64_t liveA_##k = inA_##k & ~(__builtin_amdgcn_uicmp(s0_##k, 0x7FFFFFFFu, 34) & kP0);                      \
+  uint4 r_##k;                                                                                                        \
+  asm volatile("" : "=v"(r_##k.x), "=v"(r_##k.y), "=v"(r_##k.z), "=v"(r_##k.w));                                      \
+  if (p2 < n_##k) r_##k = *reinterpret_cast<const uint4 *>(rb + (((s0_##k & 0x3FFFFFFu) + p) << 4));
+
+#define BIVX_PLACE_EVAL(k)                                                                                            \
+  {                                                                                                                   \
+    const uint32_t sqh = s2_##k >> 16, sql = s2_##k & 0xFFFFu;                                                        \
+    const uint32_t la = (r_##k.x - s1_##k) & 0xFFFFu, lb = (r_##k.z - s1_##k) & 0xFFFFu;                              \
+    const uint64_t hA = __builtin_amdgcn_uicmp(la, sqh, 37) & __builtin_amdgcn_uicmp(la + (r_##k.x >> 16), sql, 35) & liveA_##k; \
+    const uint64_t hB = __builtin_amdgcn_uicmp(lb, sqh, 37) & __builtin_amdgcn_uicmp(lb + (r_##k.z >> 16), sql, 35) & inB_##k;   \
+    /* hits of the lower lanes (both records of each), then the lane's own first record */                            \
+    uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(hA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hA, 0u));   \
+    before = __builtin_amdgcn_mbcnt_hi((uint32_t)(hB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hB, before));        \
+    const uint32_t atA = out_addr + ((wpos + before) << 2);                                                           \
+    const uint32_t nh = (uint32_t)__builtin_popcountll(hA) + (uint32_t)__builtin_popcountll(hB);                       \
+    lds_store_lanes(kP0, pos_addr + 32u * (k), wpos + before);                                                        \
+    if (store_ids && wpos + nh <= kPStage) {  /* (wavefront-uniform; a slice beyond the stage is not staged at all) */ \
+      uint32_t stepA;                                                                                                 \
+      asm("v_cndmask_b32_e64 %0, 0, 4, %1" : "=v"(stepA) : "s"(hA));  /* 4 where the lane's first record is a hit */    \
+      const uint32_t atB = atA + stepA;                                                                               \
+      lds_store_lanes(hA, atA, r_##k.y);                                                                              \
+      lds_store_lanes(hB, atB, r_##k.w);                                                                              \
+    }                                                                                                                 \
+    wpos += nh;                                                                                                       \
+  }
+
+  {
+    BIVX_PLACE_LOAD(0) BIVX_PLACE_LOAD(1) BIVX_PLACE_EVAL(0)
+    BIVX_PLACE_LOAD(2) BIVX_PLACE_EVAL(1) BIVX_PLACE_LOAD(3) BIVX_PLACE_EVAL(2)
+    BIVX_PLACE_LOAD(4) BIVX_PLACE_EVAL(3) BIVX_PLACE_LOAD(5) BIVX_PLACE_EVAL(4)
+    BIVX_PLACE_LOAD(6) BIVX_PLACE_EVAL(5) BIVX_PLACE_LOAD(7) BIVX_PLACE_EVAL(6)
+    BIVX_PLACE_EVAL(7)
+  }
+#undef BIVX_PLACE_LOAD
+#undef BIVX_PLACE_EVAL
+  if (lane == 0) out[kPlacePos + kWave] = wpos;
+  wave_sync_lds();
+  const uint32_t mine = out[kPlacePos + lane], next = out[kPlacePos + lane + 1u];
+  loff = mine;
+  cnt = next - mine;
+  return wpos;
 }
 
 #define A(f) (fresh(ka)->a.f)
@@ -764,6 +863,11 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         const bool in_slab = nonempty && wn.b - lbase <= kPKeep * (kWave / 2);
         const uint32_t nin = (uint32_t)__popcll(__ballot(in_slab)), nne = (uint32_t)__popcll(__ballot(nonempty));
         path = nin >= kSlabMinLanes && nin == nne ? 1 : 2;
+        // scattered windows of at most sixteen slots (and no query that begins 64 K above its window's base: low > high
+        // queries can): the ids go straight to their places (coop_place16)
+        if (path == 2 && (BIVX_EXP & 8) == 0 &&
+            !__any(nonempty && (wn.b - al > 16u || (qlo > wn.base && qlo - wn.base > 0xFFFFu) || (al >> 1) >= (1u << 26))))
+          path = 3;
       }
       no_ids = A(cap) == 0;
       if (path == 1) {
@@ -775,6 +879,9 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         const Window w{wn.a, wn.b, wn.base, 1u, true};
         m32 = slab_mask32(slab, lbase, w, qlo, qhi, nonempty);
         cnt = (uint32_t)__popc(m32);
+      } else if (path == 3) {
+        wtotal = coop_place16(fresh(ka)->v.rec, reinterpret_cast<uint32_t *>(slab_of_wave()), wn, nonempty, qlo, qhi,
+                              tid() & (kWave - 1), !no_ids, cnt, loff);
       } else if (path == 2) {
 #ifdef BIVX_NO_COOP
         m32 = lanes_mask32<kPKeep>(fresh(ka)->v.rec, wn, nonempty, qlo, qhi, kept_slots());
@@ -805,11 +912,14 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         const Query qy = query_of(tile);  // (rare: the query is fetched again rather than carried)
         cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, false>(v1, segs, qy, nullptr, 0, 0, nullptr);
       }
-      const uint32_t incl = wave_scan_incl(cnt);
-      loff = incl - cnt;
-      // (2^22 hits in one lane would overflow the 32-bit scan: such a slice is never staged and is counted in 64 bits)
-      const bool huge = __any(cnt >= (1u << 22));
-      wtotal = wave_last(incl);
+      bool huge = false;
+      if (path != 3) {  // (coop_place16 leaves the offsets and the total itself: at most sixteen ids per query there)
+        const uint32_t incl = wave_scan_incl(cnt);
+        loff = incl - cnt;
+        // (2^22 hits in one lane would overflow the 32-bit scan: such a slice is never staged and is counted in 64 bits)
+        huge = __any(cnt >= (1u << 22));
+        wtotal = wave_last(incl);
+      }
       staged = !huge && (no_ids ? wtotal < 65536u : path != 0 && wtotal <= kPStage);
       uint64_t wt64 = wtotal;
       lpos64 = loff;
@@ -876,6 +986,10 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         m32 &= m32 - 1u;
         *dst++ = s2[j].y;
       }
+    } else if (!no_ids && path == 3) {  // the ids lie in the keep region as they will lie in the output: a straight copy
+      const uint4 *src = reinterpret_cast<const uint4 *>(slab_of_wave());
+      uint4 *dst = reinterpret_cast<uint4 *>(stage);
+      for (uint32_t i = tid() & (kWave - 1); i < (wtotal + 3u) >> 2; i += kWave) dst[i] = src[i];
     } else if (!no_ids && path == 2) {  // the first kPKeep ids are in the lane's keep slots; a longer list re-reads the rest
       uint32_t *dst = stage + loff;
 #ifdef BIVX_NO_COOP
