@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void k_make_keys(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ ids,   // kKeySegOfId: sorted ids
                                                    uint32_t *__restrict__ seg_of,      // kKeyLow: out; kKeySegOfId: in
                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ hist0,
-                                                   uint32_t nblocks) {
+                                                   uint32_t nblocks, int first_shift) {
   if (MODE == kKeySegOfId) {
     const size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
     if (i < n) keys[i] = seg_of[ids[i]];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512) void k_make_keys(const uint32_t *__restrict__ 
         key = k.x + (lo - k.y);
       }
       keys[i] = key;
-      atomicAdd(&mine[key & 255u], 1u);
+      atomicAdd(&mine[(key >> first_shift) & 255u], 1u);
     }
   }
   __syncthreads();
@@ -729,19 +729,20 @@ int launch_bin_stats_auto(const uint32_t *d_chrom, const uint32_t *d_low, const 
 // d_hist0 (modes 0 and 1): the radix scratch — the first pass's histogram is left there (radix_sort_pairs: hist0_ready)
 int launch_make_keys(int mode, const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, const uint32_t *d_bin2seg, const uint2 *d_segkey,
-                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, void *d_hist0, hipStream_t s) {
+                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, void *d_hist0, hipStream_t s,
+                     int first_shift) {
   if (n == 0) return 0;
   const uint32_t nblocks = (uint32_t)((n + kTile - 1) / kTile);
   uint32_t *hist0 = static_cast<uint32_t *>(d_hist0);
   if (mode == kKeyDense)
     hipLaunchKernelGGL(k_make_keys<kKeyDense>, dim3(nblocks), dim3(512), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
-                       d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks);
+                       d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks, first_shift);
   else if (mode == kKeyLow)
     hipLaunchKernelGGL(k_make_keys<kKeyLow>, dim3(nblocks), dim3(512), 0, s, d_chrom, d_type, ntypes, d_low, d_high, n,
-                       d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks);
+                       d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks, first_shift);
   else
     hipLaunchKernelGGL(k_make_keys<kKeySegOfId>, dim3(grid_for(n, 512)), dim3(512), 0, s, d_chrom, d_type, ntypes, d_low,
-                       d_high, n, d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks);
+                       d_high, n, d_bin2seg, d_segkey, d_ids, d_seg_of, d_keys, hist0, nblocks, first_shift);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -753,7 +754,7 @@ size_t radix_scratch_bytes(size_t n) {
 }
 
 int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint32_t **vals_alt, size_t n,
-                     int nbits, void *d_scratch, bool vals_are_iota, bool hist0_ready, hipStream_t s) {
+                     int nbits, void *d_scratch, bool vals_are_iota, bool hist0_ready, hipStream_t s, int first_shift) {
   if (n == 0) return 0;
   const uint32_t nblocks = (uint32_t)((n + kTile - 1) / kTile);
   const size_t nh = (size_t)nblocks * kRadix;
@@ -762,8 +763,9 @@ int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint
   uint32_t *totals = offs + nh;
   bool iota = vals_are_iota;
   // (at least one pass, so that the values exist in memory when they were only implied)
-  for (int shift = 0; shift < nbits || iota; shift += kRadixBits) {
-    if (!(hist0_ready && shift == 0))  // (the key kernel left the first pass's histogram)
+  // (first_shift: the key bits below it do not take part — the build orders by directory cell, not by every bit of low)
+  for (int shift = first_shift; shift < nbits || iota; shift += kRadixBits) {
+    if (!(hist0_ready && shift == first_shift))  // (the key kernel left the first pass's histogram)
       hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kSortThreads), 0, s, *keys, n, shift, hist, nblocks);
     hipLaunchKernelGGL(k_radix_rows, dim3(kRadix), dim3(kThreads), 0, s, hist, offs, totals, nblocks);
     if (iota)

@@ -79,6 +79,7 @@ struct bivx_index {
   uint64_t nentries = 0;
   uint32_t max_cell = 0;  // most slots in any directory cell (positional hotspots)
   uint32_t max_window = 0;  // the planner's estimate of the longest usual window (ClassPlan::max_window)
+  uint32_t order_shift = 0; // IndexView::order_shift of the built index
   size_t built_n = 0;
   double build_ms = 0.0;
   // prefix workspaces of bivx_query_dev calls made without a caller workspace: one per stream (calls on one
@@ -420,6 +421,8 @@ int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, con
   return 0;
 }
 
+constexpr uint32_t kCrowdedCell = 64;  // slots in one directory cell beyond which an index is ordered by every bit of low
+
 struct ClassPlan {
   std::vector<uint32_t> bin2seg;       // nchrom * kLenBins, 0xFFFFFFFF for empty bins
   std::vector<SegDesc> segs;           // grouped by chromosome, classes by ascending length
@@ -430,6 +433,11 @@ struct ClassPlan {
   // ONE 32-bit key orders by (segment, low); key_span is the sum of the ranges (> 2^32: no such key exists)
   std::vector<uint2> segkey;
   uint64_t key_span = 0;
+  // The sort may leave out the key's low order_shift bits (the smallest cell shift of any segment; key ranges begin at
+  // multiples of 2^order_shift): the slots then come out ordered by directory cell with append order inside a cell —
+  // all a query needs, it evaluates every slot of the cells it touches — and when that saves a whole radix pass the
+  // build takes it (bivx_build). 0: the segments' key ranges are packed and every bit takes part.
+  uint32_t order_shift = 0;
   // slots a point query's window is expected to hold in the segment where that is most: count x (longest length + a
   // directory cell) / coordinate span — what tells k_query_pipe_ms's territory from the wavefront-cooperative walk's
   uint32_t max_window = 0;
@@ -533,10 +541,34 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, size_t n_tota
   plan.chrom_seg[nchrom] = (uint32_t)plan.segs.size();
   plan.nentries = table_off;
   plan.segkey.resize(plan.segs.size());
-  plan.key_span = 0;
-  for (size_t k = 0; k < plan.segs.size(); ++k) {
-    plan.segkey[k] = make_uint2((uint32_t)plan.key_span, plan.segs[k].base);  // (meaningless once the sum passes 2^32)
-    plan.key_span += (uint64_t)plan.segs[k].last - plan.segs[k].base + 1u;
+  auto lay_keys = [&](uint32_t align_bits) {
+    const uint64_t a = (1ull << align_bits) - 1ull;
+    plan.key_span = 0;
+    for (size_t k = 0; k < plan.segs.size(); ++k) {
+      plan.key_span = (plan.key_span + a) & ~a;
+      plan.segkey[k] = make_uint2((uint32_t)plan.key_span, plan.segs[k].base);  // (meaningless once the sum passes 2^32)
+      plan.key_span += (uint64_t)plan.segs[k].last - plan.segs[k].base + 1u;
+    }
+  };
+  lay_keys(0);
+  plan.order_shift = 0;
+  if (!plan.segs.empty() && plan.key_span <= 0xFFFFFFFFull && !std::getenv("BIVX_BUILD_FULL_SORT")) {  // (env: test knob)
+    uint32_t sh = 31;
+    for (const SegDesc &d : plan.segs) sh = std::min(sh, d.shift & 31u);
+    auto passes = [](uint64_t span, uint32_t from) {
+      int bits = 0;
+      while (bits < 32 && ((span - 1) >> bits) != 0) ++bits;
+      return bits > (int)from ? (bits - (int)from + 7) / 8 : 1;
+    };
+    const int full = passes(plan.key_span, 0);
+    const uint64_t packed_span = plan.key_span;
+    lay_keys(sh);
+    if (sh > 0 && plan.key_span <= 0xFFFFFFFFull && passes(plan.key_span, sh) < full) {
+      plan.order_shift = sh;
+    } else {
+      lay_keys(0);
+      (void)packed_span;
+    }
   }
   return 0;
 }
@@ -569,6 +601,7 @@ IndexView view_of(const bivx_index *idx, uint32_t svtype = 0) {
   v.nslots = idx->built_n < 0xFFFFFFFFull ? (uint32_t)idx->built_n : 0xFFFFFFFFu;
   v.max_cell = idx->max_cell;
   v.max_window = idx->max_window;
+  v.order_shift = idx->order_shift;
   v.flt_kind = BIVX_FILTER_NONE;
   v.flt_dist = 0;
   v.flt_strand = 0;
@@ -1093,7 +1126,7 @@ int bivx_build(bivx_index *idx) {
   if (!plan.bin2seg.empty()) std::memcpy(hm + off_b2s, plan.bin2seg.data(), plan.bin2seg.size() * sizeof(uint32_t));
   BIVX_HIP(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, s));
 
-  uint32_t max_cell = 0;
+  uint32_t max_cell = 0, order_shift = 0;
   if (n) {
     // 4. stable sort to (segment, low, id). One 32-bit key holds (segment, low) while the segments' coordinate spans add
     // up to less than 2^32 (see ClassPlan::segkey): then ONE sort does it and `low` comes back out of the sorted key.
@@ -1104,27 +1137,7 @@ int bivx_build(bivx_index *idx) {
     }
     // (histogram scratch of the sort, then the directory pass's short list of long empty stretches)
     BIVX_TRY(ensure_block(idx->b_radix, std::max(radix_scratch_bytes(n), finalize_gap_bytes(plan.nentries, nseg))));
-    uint32_t *kA = static_cast<uint32_t *>(idx->b_keys[0].p), *kB = static_cast<uint32_t *>(idx->b_keys[1].p);
-    uint32_t *vA = static_cast<uint32_t *>(idx->b_ids[0].p), *vB = static_cast<uint32_t *>(idx->b_ids[1].p);
     const bool dense = plan.key_span <= 0xFFFFFFFFull && !std::getenv("BIVX_BUILD_TWO_STAGE");  // (env: test knob)
-    if (dense) {
-      BIVX_TRY(launch_make_keys(kBuildKeyDense, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
-                                nullptr, nullptr, kA, idx->b_radix.p, s));
-      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for((uint32_t)(plan.key_span - 1)), idx->b_radix.p, true, true, s));
-    } else {
-      // (every interval's segment, in append order: the second sort's keys are one gather of it)
-      BIVX_TRY(ensure_block(idx->b_segof, n * 4));
-      uint32_t *d_seg_of = static_cast<uint32_t *>(idx->b_segof.p);
-      BIVX_TRY(launch_make_keys(kBuildKeyLow, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
-                                nullptr, d_seg_of, kA, idx->b_radix.p, s));
-      BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), idx->b_radix.p, true, true, s));
-      if (nseg > 1) {
-        BIVX_TRY(launch_make_keys(kBuildKeySegOfId, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg,
-                                  d_segkey, vA, d_seg_of, kA, nullptr, s));
-        BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), idx->b_radix.p, false, false, s));
-      }
-    }
-    idx->d_id = vA;  // (one of the two id blocks; it stays the index's until the next build)
     // 5. sorted (low, high) pairs and packed (record, id) pairs
     // two spare slots each: query lanes read pairs two at a time (16 B), so the pair holding the last slot may reach
     // one slot past the end
@@ -1136,9 +1149,49 @@ int bivx_build(bivx_index *idx) {
     // 6. ... and the bucket directory, by the same pass (+3 spare entries: query lanes read entries four at a time)
     BIVX_TRY(ensure_block(idx->b_table, ((size_t)plan.nentries + 3) * 4));
     idx->d_table = static_cast<uint32_t *>(idx->b_table.p);
-    BIVX_TRY(launch_finalize(dense ? kA : nullptr, idx->d_id, idx->d_low, idx->d_high, idx->d_seg, d_segkey, nseg, idx->d_se,
-                             idx->d_rec, idx->d_table, plan.nentries, idx->b_radix.p, d_scalar + 3, d_scalar + 2, n, s));
-    BIVX_HIP(hipMemcpyAsync(idx->h_scalars + 2, d_scalar + 2, 4, hipMemcpyDeviceToHost, s));
+    // The dense-key sort leaves out the key's low `skip` bits when the plan says that saves a radix pass
+    // (ClassPlan::order_shift): the slots then come out ordered by directory cell, append order inside a cell.
+    auto sort_and_finalize = [&](int skip) -> int {
+      uint32_t *kA = static_cast<uint32_t *>(idx->b_keys[0].p), *kB = static_cast<uint32_t *>(idx->b_keys[1].p);
+      uint32_t *vA = static_cast<uint32_t *>(idx->b_ids[0].p), *vB = static_cast<uint32_t *>(idx->b_ids[1].p);
+      if (dense) {
+        BIVX_TRY(launch_make_keys(kBuildKeyDense, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
+                                  nullptr, nullptr, kA, idx->b_radix.p, s, skip));
+        BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for((uint32_t)(plan.key_span - 1)), idx->b_radix.p, true, true, s,
+                                  skip));
+      } else {
+        // (every interval's segment, in append order: the second sort's keys are one gather of it)
+        BIVX_TRY(ensure_block(idx->b_segof, n * 4));
+        uint32_t *d_seg_of = static_cast<uint32_t *>(idx->b_segof.p);
+        BIVX_TRY(launch_make_keys(kBuildKeyLow, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg, d_segkey,
+                                  nullptr, d_seg_of, kA, idx->b_radix.p, s));
+        BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(plan.max_low), idx->b_radix.p, true, true, s));
+        if (nseg > 1) {
+          BIVX_TRY(launch_make_keys(kBuildKeySegOfId, idx->d_chrom, d_type, ntypes, idx->d_low, idx->d_high, n, d_bin2seg,
+                                    d_segkey, vA, d_seg_of, kA, nullptr, s));
+          BIVX_TRY(radix_sort_pairs(&kA, &vA, &kB, &vB, n, bits_for(nseg - 1), idx->b_radix.p, false, false, s));
+        }
+      }
+      idx->d_id = vA;  // (one of the two id blocks; it stays the index's until the next build)
+      BIVX_TRY(launch_finalize(dense ? kA : nullptr, idx->d_id, idx->d_low, idx->d_high, idx->d_seg, d_segkey, nseg, idx->d_se,
+                               idx->d_rec, idx->d_table, plan.nentries, idx->b_radix.p, d_scalar + 3, d_scalar + 2, n, s));
+      BIVX_HIP(hipMemcpyAsync(idx->h_scalars + 2, d_scalar + 2, 4, hipMemcpyDeviceToHost, s));
+      return 0;
+    };
+    int skip = dense ? (int)plan.order_shift : 0;
+    BIVX_TRY(sort_and_finalize(skip));
+    if (skip > 0) {
+      // A crowded cell (positional hotspot: many intervals starting inside one cell) is what long windows get trimmed
+      // inside of, by a search on low (query_device.h, wave_lower_bound_low) — that wants the cell's slots ordered by low:
+      // such an index is sorted again on every bit (it is the exception; the usual index keeps a handful of slots per cell)
+      BIVX_HIP(hipStreamSynchronize(s));
+      if (hs[2] > kCrowdedCell) {
+        BIVX_HIP(hipMemsetAsync(d_scalar + 2, 0, 8, s));  // (largest cell, the directory pass's list length)
+        skip = 0;
+        BIVX_TRY(sort_and_finalize(0));
+      }
+    }
+    order_shift = (uint32_t)skip;
   }
   BIVX_HIP(hipStreamSynchronize(s));
   if (n) max_cell = hs[2];
@@ -1149,6 +1202,7 @@ int bivx_build(bivx_index *idx) {
   idx->nentries = plan.nentries;
   idx->max_cell = max_cell;
   idx->max_window = plan.max_window;
+  idx->order_shift = order_shift;
   idx->built = true;
   idx->built_n = n;
   idx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

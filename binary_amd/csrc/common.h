@@ -61,6 +61,10 @@ struct IndexView {
   uint32_t nslots;            // sorted slots (= intervals built) — saturates at 2^32 - 1
   uint32_t max_cell;          // most slots any directory cell holds (positional hotspots make this large)
   uint32_t max_window;        // slots a query's window is EXPECTED to hold in the segment where that is most (the planner's estimate)
+  // Slots are ordered by (segment, (low - segment base) >> order_shift, id): 0 = by every bit of low; otherwise by directory
+  // cell (order_shift <= every segment's cell shift) with append order inside a cell — what a query needs, since it
+  // evaluates every slot of the cells it touches; the build then sorts one radix pass less (capi.hip, bivx_build)
+  uint32_t order_shift;
   // optional post-filter fused into the enumeration (bivx_filter): a candidate must pass it as well
   uint32_t flt_kind;          // BIVX_FILTER_*
   uint32_t flt_dist;
@@ -139,14 +143,15 @@ int launch_gather_u8(const uint8_t *d_src, const uint32_t *d_ids, size_t n, size
 enum : int { kBuildKeyDense = 0, kBuildKeyLow = 1, kBuildKeySegOfId = 2 };
 int launch_make_keys(int mode, const uint32_t *d_chrom, const uint8_t *d_type, uint32_t ntypes, const uint32_t *d_low,
                      const uint32_t *d_high, size_t n, const uint32_t *d_bin2seg, const uint2 *d_segkey,
-                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, void *d_hist0, hipStream_t s);
+                     const uint32_t *d_ids, uint32_t *d_seg_of, uint32_t *d_keys, void *d_hist0, hipStream_t s,
+                     int first_shift = 0);
 // stable LSD radix sort of (key, val) pairs on key bits [0, nbits); result ends in (*keys, *vals)
 // (the pointers are swapped with the alt buffers as passes ping-pong). scratch: radix_scratch_bytes(n).
 // vals_are_iota: the values are 0 .. n-1 and need not exist in memory yet (the first pass writes them).
 // hist0_ready: launch_make_keys left the first pass's histogram in d_scratch.
 size_t radix_scratch_bytes(size_t n);
 int radix_sort_pairs(uint32_t **keys, uint32_t **vals, uint32_t **keys_alt, uint32_t **vals_alt, size_t n,
-                     int nbits, void *d_scratch, bool vals_are_iota, bool hist0_ready, hipStream_t s);
+                     int nbits, void *d_scratch, bool vals_are_iota, bool hist0_ready, hipStream_t s, int first_shift = 0);
 // se[], rec[] and the bucket directory (with its three spare entries) from the sorted ids (and the sorted dense keys;
 // d_keys == nullptr: low is gathered by id). d_gaps: finalize_gap_bytes() of scratch; *d_ngaps and *d_max_cell must be
 // zero; *d_max_cell receives the largest number of slots any directory cell holds.

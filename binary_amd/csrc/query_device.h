@@ -302,11 +302,17 @@ __device__ __forceinline__ uint64_t slab_mask64(const uint4 *slab, uint32_t lbas
 // 64 lanes probe 64 evenly spaced slots, one __ballot tells which gap holds the answer, repeat. Used to trim long
 // candidate windows (many intervals starting inside one directory cell) to the slots whose low lies in
 // [q.low - maxlen, q.high] before they are scanned. All 64 lanes must call it with the same arguments.
-__device__ __forceinline__ uint32_t wave_lower_bound_low(const uint2 *se, uint32_t a, uint32_t b, uint32_t x, int lane) {
+// `gran`: the slots are ordered by (low - base) >> gran only (IndexView::order_shift: by directory cell, append order
+// inside a cell; 0: by low itself) — the comparison is made at that granularity, so the answer is the first slot of x's
+// cell: a superset of the exact range, which is all a window has to be (every slot in it is evaluated).
+__device__ __forceinline__ uint32_t wave_lower_bound_low(const uint2 *se, uint32_t a, uint32_t b, uint32_t x, int lane,
+                                                         uint32_t base = 0, uint32_t gran = 0) {
+  const uint32_t xk = x > base ? (x - base) >> gran : 0u;
+  auto key_ge = [&](uint32_t p) { return ((se[p].x - base) >> gran) >= xk; };
   while (b - a > (uint32_t)kWave) {
     const uint32_t step = (b - a + kWave - 1) / kWave;
     const uint32_t p = a + step * (uint32_t)lane;
-    const bool ge = p < b ? se[p].x >= x : true;  // lows ascend inside a segment: the ballot is 0..01..1
+    const bool ge = p < b ? key_ge(p) : true;  // keys ascend inside a segment: the ballot is 0..01..1
     const uint64_t m = __ballot(ge);
     const uint32_t first = m ? (uint32_t)__ffsll((long long)m) - 1u : (uint32_t)kWave;
     const uint32_t nb = first < (uint32_t)kWave ? min(a + step * first, b) : b;
@@ -315,7 +321,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound_low(const uint2 *se, uint32
     b = nb;
   }
   const uint32_t p = a + (uint32_t)lane;
-  const uint64_t m = __ballot(p < b ? se[p].x >= x : true);
+  const uint64_t m = __ballot(p < b ? key_ge(p) : true);
   const uint32_t first = m ? (uint32_t)__ffsll((long long)m) - 1u : (uint32_t)kWave;
   return min(a + first, b);
 }
@@ -506,8 +512,18 @@ __device__ __forceinline__ uint32_t enumerate_hits(const IndexView &v, const Seg
       const uint32_t cl = of_src(lo), ch = of_src(hi);
       const uint32_t cx = F ? of_src(qy.aux) : 0u;
       if (cb - ca > kTrim) {  // long window: trim it to the slots with low in [q.low - maxlen, q.high]
-        ca = wave_lower_bound_low(v.se, ca, cb, of_src(xlow), lane);
-        if (ch != 0xFFFFFFFFu) cb = wave_lower_bound_low(v.se, ca, cb, ch + 1u, lane);
+        // (an index ordered by directory cell — IndexView::order_shift — is trimmed to whole cells: the segment's base and
+        // cell shift are read again from its descriptor, this path is rare)
+        uint32_t cbase = 0, gran = 0;
+        if (v.order_shift) {
+          const SegDesc *sd = segs + of_src(qy.s0) + k;
+          cbase = sd->base;
+          gran = sd->shift & 31u;
+        }
+        ca = wave_lower_bound_low(v.se, ca, cb, of_src(xlow), lane, cbase, gran);
+        // first slot whose key is beyond q.high's: at cell granularity that is the first slot of the NEXT cell
+        const uint32_t nx = gran ? (((ch > cbase ? (ch - cbase) >> gran : 0u) + 1u) << gran) + cbase : ch + 1u;
+        if (nx > ch) cb = wave_lower_bound_low(v.se, ca, cb, nx, lane, cbase, gran);  // (no wrap past 2^32)
       }
       auto is_hit = [&](uint32_t j) {
         const uint2 e = v.se[j];

@@ -908,6 +908,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe(IndexView v_in, Pip
         v1.flt_strand = 0;
         v1.flt_qaux = nullptr;
         v1.flt_iaux = nullptr;
+        v1.order_shift = p->v.order_shift;
         v1.err = nullptr;
         const Query qy = query_of(tile);  // (rare: the query is fetched again rather than carried)
         cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, false>(v1, segs, qy, nullptr, 0, 0, nullptr);
@@ -1326,6 +1327,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
         v1.flt_strand = 0;
         v1.flt_qaux = nullptr;
         v1.flt_iaux = nullptr;
+        v1.order_shift = p->v.order_shift;
         v1.err = nullptr;
         const Query qy = query_of(tile);
         cnt = enumerate_hits<Mode::Count, false, false, kPKeep, kRows, false>(v1, segs, qy, nullptr, 0, 0, nullptr);
@@ -1745,6 +1747,7 @@ __global__ __launch_bounds__(kMsThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Ind
       v1.flt_strand = p->v.flt_strand;
       v1.flt_qaux = nullptr;
       v1.flt_iaux = p->v.flt_iaux;
+      v1.order_shift = p->v.order_shift;
       v1.err = nullptr;
       cnt = enumerate_hits<Mode::Count, F, true, kKeep, kRows, false>(v1, segs, qy, nullptr, 0, 0, nullptr);
     }

@@ -154,8 +154,10 @@ def _index_order_csr(idx, qlo, qhi, qc):
 
 
 def test_build_two_stage_sort_equals_dense_key_sort(monkeypatch):
-    """The same intervals built both ways give the same index: same CSR in INDEX order, bit for bit (index order is
-    (length class, low, id): it exposes the sorted arrays themselves)."""
+    """The same intervals built both ways give the same index: same CSR in INDEX order, bit for bit — when both sort on
+    every bit of low (BIVX_BUILD_FULL_SORT; index order is then (length class, low, id) and exposes the sorted arrays
+    themselves). The default dense-key build may order by directory cell instead (round 4: one radix pass less): same
+    offsets, same lists as sets, and the same lists bit for bit once ordered by id."""
     from binary_amd import IntervalIndex
     chrom, low, high, typ = _typed_multiclass_index(9)
     low[::7] = low[7]                                   # many equal lows: ties must keep append order
@@ -165,15 +167,24 @@ def test_build_two_stage_sort_equals_dense_key_sort(monkeypatch):
     qc = rng.integers(0, 3, q).astype(np.uint32)
     qlo = rng.integers(0, 1_000_000, q).astype(np.uint32)
     qhi = (qlo + rng.integers(0, 2000, q)).astype(np.uint32)
-    res = []
-    for two_stage in (False, True):
-        if two_stage:
+    res, res_sorted = [], []
+    for route in ("dense full", "two-stage", "default"):
+        monkeypatch.delenv("BIVX_BUILD_TWO_STAGE", raising=False)
+        monkeypatch.delenv("BIVX_BUILD_FULL_SORT", raising=False)
+        if route == "two-stage":
             monkeypatch.setenv("BIVX_BUILD_TWO_STAGE", "1")
+        elif route == "dense full":
+            monkeypatch.setenv("BIVX_BUILD_FULL_SORT", "1")
         with IntervalIndex(0) as idx:
             idx.insert_node(low, high, chrom, svtype=typ)
             idx.build()
             res.append(_index_order_csr(idx, qlo, qhi, qc))
+            off, hits = idx.find_overlaps(qlo, qhi, qc, sort_by_id=True)
+            res_sorted.append((off.copy(), np.array(hits, copy=True)))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for k in (1, 2):
+        assert np.array_equal(res_sorted[0][0], res_sorted[k][0]) and np.array_equal(res_sorted[0][1], res_sorted[k][1])
+    assert np.array_equal(res[0][0], res[2][0])
     exp = _brute(chrom, low, high, np.ones(low.size, bool), qc[:300], qlo[:300], qhi[:300])
     for k, e in enumerate(exp):
         assert np.array_equal(np.sort(res[0][1][int(res[0][0][k]):int(res[0][0][k + 1])].astype(np.int64)), e)
