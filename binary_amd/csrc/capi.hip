@@ -1510,10 +1510,6 @@ int bivx_debug_corrupt_workspace(const bivx_index *idx, void *stream) {
     return BIVX_E_STATE;
   }
   BIVX_HIP(hipMemsetAsync(it->second.p, 0x7F, sizeof(uint32_t), s));  // ticket word: far beyond any grid
-  // (... and the pipelined kernels' eight ticket shards: the last 2 KiB of the workspace, 256 bytes apart)
-  for (int k = 0; k < 8; ++k)
-    BIVX_HIP(hipMemsetAsync(static_cast<char *>(it->second.p) + bivx_query_workspace_bytes(0) - 2048 + 256 * k, 0x7F,
-                            sizeof(uint32_t), s));
   return 0;
 }
 

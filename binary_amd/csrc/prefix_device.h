@@ -23,13 +23,6 @@ constexpr uint32_t kWsTicket = 0, kWsCarry = 8, kWsDone = 16, kWsNeedSort = 24, 
 // the pipelined kernels' list of slices behind the status array (u64 index; u32 entries, 16 per tile: a tile has 15
 // slices and in the worst case every one of them is listed)
 constexpr uint32_t kWsList = kWsStatus + kFMaxGroups + kFMaxTiles, kWsListWords = kFMaxTiles * 8;
-// The pipelined kernels' FIRST tickets, in kTicketShards counters on lines of their own behind the list: shard k hands
-// out the tiles k, k + 8, k + 16, ... below gridDim.x. One word takes ~88 returning atomics per microsecond; a launch's 512
-// workgroups all draw their first ticket within two microseconds of each other, and the last of them had its ticket 6 us
-// after the first (profiles/r04_small_batch_timeline.txt). Later tickets come from ws[kWsTicket] as before.
-constexpr uint32_t kTicketShards = 8, kTicketStride = 32;  // (stride in u64 words: 256 bytes)
-constexpr uint32_t kWsTickets = kWsList + kWsListWords;
-constexpr uint32_t kWsWords = kWsTickets + kTicketShards * kTicketStride;
 constexpr uint32_t kDoneShift = 44;  // unordered output: ws[kWsDone] = departures << 44 | ids reserved by this launch
 // k_query_fused flags: index-owned workspace; last launch of the call; bits 8-15: log2 of the bound on a prefix
 // wait in ticks of the 100 MHz constant clock (0 = kWaitLog2Default)

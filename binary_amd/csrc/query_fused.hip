@@ -436,8 +436,8 @@ __global__ __launch_bounds__(kFThreads, F ? 4 : BIVX_FUSED_WAVES) void k_query_f
 
 size_t fused_workspace_bytes(size_t q) {
   (void)q;
-  // header words, group words, tile words, the pipelined kernels' list of slices left for k_fill_slices, their tickets
-  return (size_t)kWsWords * sizeof(uint64_t);
+  // header words, group words, tile words, then the pipelined kernels' list of slices left for k_fill_slices
+  return ((size_t)kWsList + kWsListWords) * sizeof(uint64_t);
 }
 
 int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow,
@@ -480,11 +480,8 @@ int launch_query_fused(const IndexView &v, const uint32_t *d_qchrom, const uint3
     const size_t tile_q = use_pipe ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
     const unsigned tiles = (unsigned)((q1 - q0 + tile_q - 1) / tile_q);
     const size_t tile_small = use_ms ? ms_tile : use_pipe || try_dense ? pipe_queries_per_launch() / kFMaxTiles : (size_t)kFTile;
-    if (!self_clean && (!unordered || use_pipe)) {
+    if (!self_clean && (!unordered || use_pipe))
       BIVX_HIP(hipMemsetAsync(d_ws, 0, ((q1 - q0 + tile_small - 1) / tile_small + kFMaxGroups + kWsStatus) * sizeof(uint64_t), s));
-      if (use_pipe || try_dense || use_ms)  // (the pipelined kernels' ticket counters live behind the list)
-        BIVX_HIP(hipMemsetAsync(ws + kWsTickets, 0, (size_t)kTicketShards * kTicketStride * sizeof(uint64_t), s));
-    }
     const dim3 grid(tiles), block(kFThreads);
     const bool lds = fits_lds(v), flt = v.flt_kind != BIVX_FILTER_NONE;
     // BIVX_PREFIX_WAIT_LOG2 (tests): bound of a prefix wait as log2 of 10 ns ticks; 1 makes every wait that is not

@@ -503,7 +503,6 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
   uint32_t drawn = 0, published = 0, grouped = 0, swept = 0;
   uint32_t last_tile = 0;   // ticket of the newest drawn tile
   bool drawing = true;      // no ticket beyond the batch yet
-  bool first_round_over = false;  // every tile of the sharded first round is known to be drawn (see the ticket below)
   uint64_t stuck_since = 0; // when the oldest unswept tile's sweep was first found blocked
   const bool flat = pc.ntiles <= kFlatTiles;
   for (;;) {
@@ -519,71 +518,26 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
       TileSlot &sl = s_slot[drawn % kRing];
       // (the slot's last user was iteration drawn - kRing: swept, but every worker must also be through with it)
       if (want && (drawn < kRing || lds_load(&sl.flushed) == (uint32_t)NW)) {
-        // The ticket. The launch's first gridDim.x tiles are handed out by eight sharded counters (prefix_device.h,
-        // kTicketShards): a workgroup's FIRST draw takes from shard blockIdx % 8 without looking — the burst of first
-        // draws is what one counter word cannot take. Every later draw first makes sure that no first-round tile is left
-        // (a workgroup that was dispatched late, or not yet, has not drawn its own: somebody resident must, or the sweeps
-        // behind it would wait for a tile nobody holds) — a fresh look at the eight counters, usually one — and then takes
-        // from the single counter as before, which starts behind the first round.
-        uint64_t *const wsp = A(ws);
-        unsigned int *const tk = reinterpret_cast<unsigned int *>(wsp + kWsTickets);
-        auto shard_tiles = [&](uint32_t k) { return (gridDim.x + kTicketShards - 1 - k) / kTicketShards; };  // tiles of shard k
-        uint32_t tile = 0xFFFFFFFFu;
-        bool got = false;
-        if (drawn == 0) {
-          const uint32_t k = blockIdx.x & (kTicketShards - 1);
-          uint32_t c = 0;
-          if (lane == 0) c = atomicAdd(tk + k * (kTicketStride * 2), 1u);
-          c = __builtin_amdgcn_readfirstlane(c);
-          if (c < shard_tiles(k)) {
-            tile = c * kTicketShards + k;
-            got = true;
-          } else if (c > shard_tiles(k) + 2u * gridDim.x) {
-            // A shard is legitimately overshot — a workgroup that was dispatched late finds its first-round tile taken by
-            // one that came before it — but by no more than a draw or two per workgroup: beyond that the counters were not
-            // zero when the launch began (a launch that died half-way, a caller workspace that was not cleared) and
-            // nothing this launch writes can be trusted. Say so; the workgroup leaves at once (tile 0xFFFFFFFF).
-            if (lane == 0) raise_error(pc.err, kErrWorkspace);
-            got = true;
-          }
-        }
-        while (!got && !first_round_over) {
-          // fresh values (a returning atomic: a plain load may be served from this XCD's L2)
-          uint32_t next = 0xFFFFFFFFu;
-          if (lane < (int)kTicketShards) {
-            const uint32_t c = atomicAdd(tk + lane * (kTicketStride * 2), 0u);
-            if (c < shard_tiles((uint32_t)lane)) next = c * kTicketShards + (uint32_t)lane;
-          }
-          const uint32_t m = wave_min(next);
-          if (m == 0xFFFFFFFFu) {
-            first_round_over = true;
-            break;
-          }
-          const uint32_t k = m & (kTicketShards - 1);
-          uint32_t c = 0;
-          if (lane == 0) c = atomicAdd(tk + k * (kTicketStride * 2), 1u);
-          c = __builtin_amdgcn_readfirstlane(c);
-          if (c < shard_tiles(k)) {
-            tile = c * kTicketShards + k;
-            got = true;
-          }
-        }
-        if (!got) {
-          uint32_t t = 0;
-          if (lane == 0) t = atomicAdd(reinterpret_cast<unsigned int *>(wsp + kWsTicket), 1u);
-          tile = gridDim.x + __builtin_amdgcn_readfirstlane(t);
-          // Every workgroup draws exactly one ticket beyond the batch, so none can reach ntiles + gridDim.x unless the
-          // counter was not zero when the launch began: then tiles were skipped and nothing this launch wrote can be
-          // trusted. Say so.
-          if (tile >= pc.ntiles + gridDim.x && lane == 0) raise_error(pc.err, kErrWorkspace);
-        }
+        // The ticket: ONE counter for the launch. (Round 4 tried eight sharded counters for the launch's first gridDim.x
+        // tiles — the burst of 512 first draws queues on one word for up to 6 us, profiles/r04_small_batch_timeline.txt —
+        // with the later draws stealing what a late workgroup had not drawn. It is unsafe: a workgroup's tiles must come in
+        // ASCENDING order, because the flush of its tile k waits for a sweep over every smaller tile, and a smaller tile
+        // drawn later sits behind k in the same workgroup's ring — the workers that would count it are the ones waiting.
+        // With part of a launch resident (two processes on one card) exactly that happened: timeouts. One counter hands
+        // every workgroup ascending tiles by construction.)
+        uint32_t tile = 0;
         if (lane == 0) {
+          tile = atomicAdd(reinterpret_cast<unsigned int *>(A(ws) + kWsTicket), 1u);
           sl.arrived = 0;
           sl.flushed = 0;
           sl.tile = tile;
           lds_store(&sl.gen_ticket, drawn + 1);
         }
-        last_tile = tile;
+        last_tile = __builtin_amdgcn_readfirstlane(tile);
+        // Every workgroup draws exactly one ticket beyond the batch, so none can reach ntiles + gridDim.x unless
+        // the counter was not zero when the launch began (a launch that died half-way, a caller workspace that was
+        // not cleared): then tiles were skipped and nothing this launch wrote can be trusted. Say so.
+        if (last_tile >= pc.ntiles + gridDim.x && lane == 0) raise_error(pc.err, kErrWorkspace);
         if (last_tile >= pc.ntiles) drawing = false;  // the workers see it, flush what is pending and leave
         ++drawn;
         progress = true;
@@ -667,7 +621,6 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
         pc.status[t] = 0;
         if (t < (pc.ntiles + kWave - 1) / kWave) pc.group[t] = 0;
       }
-      if (lane < (int)kTicketShards) ws[kWsTickets + (uint32_t)lane * kTicketStride] = 0;
       if (lane == 0) {
         ws[kWsTicket] = 0;
         ws[kWsDone] = 0;

@@ -473,3 +473,22 @@ def test_errors_are_surfaced_by_the_pipelined_kernel_too():
         idx.query_device(d_qlo, d_qhi, off, hits)       # cleared before this launch
         idx.stream_status()
         assert torch.equal(off, ref_off) and torch.equal(hits, ref_hits)
+
+
+def test_two_processes_share_the_gpu():
+    """Two PROCESSES launch the pipelined kernels on one card at the same time (what `bench.py --gpus 2` rehearsed on a
+    one-GPU box does): persistent workgroups of two launches compete for the CUs and a launch may run for a long time with
+    only part of its grid resident. Round 4's sharded first tickets deadlocked exactly here (a workgroup was handed a
+    smaller tile after a larger one: the flush of the larger waits for a sweep over the smaller, which the same workers
+    would count later) — every call must finish promptly, with the same totals in both processes."""
+    import ast
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "two_process_stress.py"), "1e7", "80"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = ast.literal_eval([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    res = out["results (rank, ids, slowest round s)"]
+    assert out["exit codes"] == [0, 0] and len(res) == 2 and res[0][1] == res[1][1] and max(x[2] for x in res) < 5.0, out
