@@ -26,6 +26,7 @@
 // workgroup (which never wait for other workgroups) and for tiles with SMALLER tickets, all drawn by resident
 // workgroups; the smallest unpublished tile can therefore always be finished. Waits on other workgroups are bounded
 // by wall time and an expired one fails the call (prefix_device.h).
+#include <atomic>
 #include <cstdlib>
 
 #include "prefix_device.h"
@@ -1886,16 +1887,29 @@ bool pipe_ms_eligible(const IndexView &v, size_t q, uint64_t cap, bool unordered
 size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }
 size_t pipe_ms_queries_per_launch() { return (size_t)kFMaxTiles * kMsTile; }
 
+// Compute units of the calling thread's current device, looked up once per device and process (a launch used to ask the
+// runtime every time: hipGetDevice + hipDeviceGetAttribute are microseconds on the path of a 40 us call). The environment
+// knobs below stay per launch: tests switch them between calls.
+static unsigned cus_of_current_device() {
+  static std::atomic<unsigned> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256u;
+  unsigned c = cache[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    int cus = 0;
+    c = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 ? (unsigned)cus : 256u;
+    cache[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+
 int launch_query_pipe_ms(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                          size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
                          int flags, uint32_t skip_seq, hipStream_t s) {
   const unsigned tiles = (unsigned)((q1 - q0 + kMsTile - 1) / kMsTile);
   unsigned wgs = 512;
   {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      wgs = 2u * (unsigned)cus;  // two workgroups of 512 threads per CU: 128 registers, 79 KB of LDS each
+    wgs = 2u * cus_of_current_device();  // two workgroups of 512 threads per CU: 128 registers, 79 KB of LDS each
     if (const char *e = std::getenv("BIVX_PIPE_WGS")) {
       const long w = std::atol(e);
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
@@ -1923,10 +1937,7 @@ int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32
   const unsigned tiles = (unsigned)((q1 - q0 + kPTile - 1) / kPTile);
   unsigned wgs = 512;
   {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      wgs = 2u * (unsigned)cus;  // two workgroups of 1024 threads are resident per CU (64 VGPRs, 71 KiB of LDS)
+    wgs = 2u * cus_of_current_device();  // two workgroups of 1024 threads are resident per CU (64 VGPRs, 71 KiB of LDS)
     if (const char *e = std::getenv("BIVX_PIPE_WGS")) {  // tuning / test knob
       const long w = std::atol(e);
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
@@ -1955,10 +1966,7 @@ int launch_query_pipe_dense(const IndexView &v, const uint32_t *d_qchrom, const 
   const unsigned tiles = (unsigned)((q1 - q0 + kPTile - 1) / kPTile);
   unsigned wgs = 512;
   {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      wgs = 2u * (unsigned)cus;
+    wgs = 2u * cus_of_current_device();
     if (const char *e = std::getenv("BIVX_PIPE_WGS")) {
       const long w = std::atol(e);
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;
@@ -2172,10 +2180,7 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
   const int flags = (self_clean ? kFlagSelfClean : 0) | kFlagFinal | kFlagSorted;
   unsigned wgs = 512;
   {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      wgs = 2u * (unsigned)cus;
+    wgs = 2u * cus_of_current_device();
     if (const char *e = std::getenv("BIVX_PIPE_WGS")) {
       const long w = std::atol(e);
       if (w >= 1 && w <= 65536) wgs = (unsigned)w;

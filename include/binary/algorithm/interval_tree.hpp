@@ -28,6 +28,7 @@
 #include <binary/algorithm/rb_tree.hpp>
 #include <binary/concepts.hpp>
 #include <cassert>
+#include <concepts>
 #include <cstdint>
 #include <cstdlib>
 #include <limits>
@@ -183,8 +184,17 @@ namespace binary::algorithm::tree {
     using raw_pointer = typename NodeType::raw_pointer;
     using reference_pointer = typename NodeType::reference_pointer;
     using interval_type = typename NodeType::interval_type;
-    static_assert(std::same_as<key_type, std::uint32_t> || std::same_as<key_type, std::int32_t>,
-                  "the MI355X backend evaluates the closed-interval predicate on 32-bit integer keys");
+    // The device evaluates the closed-interval predicate on 32-bit unsigned coordinates. uint32_t / int32_t keys map onto
+    // them one to one (the reference's two aliases, interval_tree.hpp:135-136); any other INTEGER key type (int64_t,
+    // uint64_t, int16_t ...; the reference takes every totally ordered key, rb_tree.hpp:20-21) goes through an
+    // order-preserving window: key - (smallest coordinate of the tree), which must fit 32 bits — genomic coordinates do.
+    // A tree whose coordinates span more than 2^32 - 1 throws std::domain_error at its first query (no silent slow path);
+    // queries beyond the window are clamped or answered empty on the spot, which is exact because no stored interval
+    // lies out there. Keys that are not integers (double, strings) have no device form: a compile-time error.
+    static_assert(std::integral<key_type> && !std::same_as<key_type, bool>,
+                  "the MI355X backend evaluates the closed-interval predicate on integer keys (any width; the coordinates "
+                  "of one tree must span less than 2^32)");
+    static constexpr bool kNative32 = std::same_as<key_type, std::uint32_t> || std::same_as<key_type, std::int32_t>;
 
     /// device: HIP device ordinal (default 0, or the BIVX_DEVICE environment variable).
     explicit IntervalTree(int device = default_device()) {
@@ -238,7 +248,8 @@ namespace binary::algorithm::tree {
         return std::nullopt;
       }
       sync();
-      const std::uint32_t lo = detail::to_u32(q.low), hi = detail::to_u32(q.high);
+      std::uint32_t lo = 0, hi = 0;
+      if (!map_query(q, lo, hi)) return std::nullopt;  // (beyond every stored coordinate)
       std::uint32_t first = BIVX_NO_HIT;
       detail::check(bivx_any(index_.get(), nullptr, &lo, &hi, 1, &first), "bivx_any");
       if (first == BIVX_NO_HIT) return std::nullopt;
@@ -269,11 +280,34 @@ namespace binary::algorithm::tree {
     /// Many queries in one device pass; ids are insertion indices, ascending inside each query.
     [[nodiscard]] auto find_overlaps_batch(std::span<const interval_type> queries) const -> OverlapBatch {
       std::vector<std::uint32_t> lo(queries.size()), hi(queries.size());
-      for (std::size_t i = 0; i < queries.size(); ++i) {
-        lo[i] = detail::to_u32(queries[i].low);
-        hi[i] = detail::to_u32(queries[i].high);
+      if constexpr (kNative32) {
+        for (std::size_t i = 0; i < queries.size(); ++i) {
+          lo[i] = detail::to_u32(queries[i].low);
+          hi[i] = detail::to_u32(queries[i].high);
+        }
+        return find_overlaps_batch(lo, hi);
+      } else {
+        sync();  // (the window's base is the tree's smallest coordinate)
+        // queries that lie beyond every stored coordinate have no hit and are left out of the device batch
+        std::vector<std::size_t> sent;
+        sent.reserve(queries.size());
+        std::size_t m = 0;
+        for (std::size_t i = 0; i < queries.size(); ++i)
+          if (map_query(queries[i], lo[m], hi[m])) {
+            sent.push_back(i);
+            ++m;
+          }
+        lo.resize(m);
+        hi.resize(m);
+        OverlapBatch part = find_overlaps_batch(lo, hi);
+        if (m == queries.size()) return part;
+        OverlapBatch b;
+        b.ids = std::move(part.ids);
+        b.offsets.assign(queries.size() + 1, 0);
+        for (std::size_t k = 0; k < m; ++k) b.offsets[sent[k] + 1] = part.offsets[k + 1] - part.offsets[k];
+        for (std::size_t i = 0; i < queries.size(); ++i) b.offsets[i + 1] += b.offsets[i];
+        return b;
       }
-      return find_overlaps_batch(lo, hi);
     }
     [[nodiscard]] auto find_overlaps_batch(std::span<const std::uint32_t> low_u32,
                                            std::span<const std::uint32_t> high_u32) const -> OverlapBatch {
@@ -322,6 +356,30 @@ namespace binary::algorithm::tree {
       return e ? std::atoi(e) : 0;
     }
 
+    // key -> device coordinate (a stored coordinate: inside the window by construction)
+    static constexpr auto widen(key_type k) -> std::uint64_t {
+      if constexpr (std::is_signed_v<key_type>) return static_cast<std::uint64_t>(static_cast<std::int64_t>(k)) ^ (1ull << 63);
+      else return static_cast<std::uint64_t>(k);
+    }
+    auto map_key(key_type k) const -> std::uint32_t {
+      if constexpr (kNative32) return detail::to_u32(k);
+      else return static_cast<std::uint32_t>(widen(k) - widen(base_));
+    }
+    // a query's ends as device coordinates; false: it lies beyond every stored coordinate and has no hit. Ends outside the
+    // window are clamped to it — exact, since every stored coordinate is inside (call after sync()).
+    auto map_query(interval_type const &q, std::uint32_t &lo, std::uint32_t &hi) const -> bool {
+      if constexpr (kNative32) {
+        lo = detail::to_u32(q.low);
+        hi = detail::to_u32(q.high);
+        return true;
+      } else {
+        if (!have_window_ || q.high < base_ || q.low > top_) return false;
+        lo = q.low < base_ ? 0u : map_key(q.low);
+        hi = q.high > top_ ? map_key(top_) : map_key(q.high);
+        return true;
+      }
+    }
+
     void push(interval_type &&i) {
       items_.push_back(std::move(i));
       shape_.reset();  // structure and pre-order ranks are stale
@@ -332,12 +390,36 @@ namespace binary::algorithm::tree {
       // const queries on a built tree may run concurrently (the reference relies on it, mapper.cpp:130-141): the
       // lazy upload / build and the lazily replayed host tree are therefore serialised
       std::lock_guard<std::mutex> lock(*lazy_);
+      if constexpr (!kNative32) {
+        // the window [base_, base_ + 2^32 - 1] must hold every coordinate: a new one outside it moves the window, and
+        // everything is appended again under the new base
+        bool moved = false;
+        for (std::size_t k = synced_; k < items_.size(); ++k)
+          for (const key_type c : {items_[k].low, items_[k].high}) {
+            if (!have_window_) {
+              base_ = top_ = c;
+              have_window_ = true;
+            } else if (c < base_) {
+              base_ = c;
+              moved = true;
+            } else if (c > top_) {
+              top_ = c;
+            }
+          }
+        if (have_window_ && widen(top_) - widen(base_) > 0xFFFFFFFFull)
+          throw std::domain_error("IntervalTree: the tree's coordinates span more than 2^32 - 1, which the device index "
+                                  "(32-bit coordinates relative to the smallest one) cannot hold");
+        if (moved && synced_ != 0) {
+          detail::check(bivx_clear(index_.get()), "bivx_clear");
+          synced_ = 0;
+        }
+      }
       if (synced_ < items_.size()) {
         const std::size_t n = items_.size() - synced_;
         std::vector<std::uint32_t> lo(n), hi(n);
         for (std::size_t k = 0; k < n; ++k) {
-          lo[k] = detail::to_u32(items_[synced_ + k].low);
-          hi[k] = detail::to_u32(items_[synced_ + k].high);
+          lo[k] = map_key(items_[synced_ + k].low);
+          hi[k] = map_key(items_[synced_ + k].high);
         }
         detail::check(bivx_append(index_.get(), nullptr, lo.data(), hi.data(), n), "bivx_append");
         synced_ = items_.size();
@@ -389,6 +471,8 @@ namespace binary::algorithm::tree {
     std::vector<interval_type> items_;  // insertion order; id == index
     std::unique_ptr<bivx_index, detail::IndexDeleter> index_;
     mutable std::size_t synced_{0};
+    mutable key_type base_{}, top_{};   // (keys other than 32-bit ones) smallest / largest stored coordinate
+    mutable bool have_window_{false};
     HitOrder order_{HitOrder::Insertion};
     std::unique_ptr<std::mutex> lazy_{std::make_unique<std::mutex>()};  // (behind a pointer: the tree stays movable)
     mutable std::unique_ptr<Shape> shape_;

@@ -265,6 +265,87 @@ static void gpu_cases() {
     CHECK_EQ(got[0], expect0);
     for (int w = 1; w < 8; ++w) CHECK(got[w] >= expect0 - 40 && got[w] <= expect0 + 40);
   }
+  {  // 64-bit keys (the reference takes any totally ordered key, rb_tree.hpp:20-21): coordinates far
+     // beyond 2^32 through the window relative to the tree's smallest coordinate, signed and unsigned; queries that reach
+     // beyond the window or lie outside it; a later insert BELOW the window's base (everything is appended again); a tree
+     // whose coordinates span more than 2^32 - 1 refuses loudly
+    using I64 = BaseInterval<std::int64_t>;
+    using U64 = BaseInterval<std::uint64_t>;
+    IntervalTree<IntervalNode<I64>> t{};
+    const std::int64_t B = 1'000'000'000'000;  // 1e12
+    std::vector<I64> all;
+    std::uint64_t st = 99;
+    auto rnd = [&](std::uint64_t n) {
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      return (st >> 33) % n;
+    };
+    for (int i = 0; i < 3000; ++i) {
+      const std::int64_t lo = B + (std::int64_t)rnd(2'000'000);
+      all.emplace_back(lo, lo + (std::int64_t)rnd(3000));
+      t.insert_node(all.back().low, all.back().high);
+    }
+    auto brute = [&](I64 const &q) {
+      std::vector<std::pair<std::int64_t, std::int64_t>> v;
+      for (auto const &x : all)
+        if (x.low <= q.high && q.low <= x.high) v.emplace_back(x.low, x.high);
+      return v;
+    };
+    auto same = [&](I64 const &q) {
+      auto got = t.find_overlaps(q.low, q.high);
+      auto exp = brute(q);
+      if (got.size() != exp.size()) return false;
+      for (std::size_t k = 0; k < got.size(); ++k)   // (insertion order on both sides)
+        if (got[k].low != exp[k].first || got[k].high != exp[k].second) return false;
+      return true;
+    };
+    CHECK(same(I64{B + 1000, B + 5000}));
+    CHECK(same(I64{B - 10, B + 100}));                 // reaches below the window: clamped
+    CHECK(same(I64{-5, B + 2'500'000}));               // everything
+    CHECK(same(I64{B + 1'999'000, B + 70'000'000'000}));  // reaches far beyond the window's top
+    CHECK_EQ(t.find_overlaps(std::int64_t{0}, std::int64_t{B - 1}).size(), 0u);                    // wholly below
+    CHECK_EQ(t.find_overlaps(std::int64_t{B + 9'000'000}, std::int64_t{B + 9'000'100}).size(), 0u);  // wholly above
+    CHECK(!t.find_overlap(std::int64_t{-100}, std::int64_t{-1}).has_value());
+    CHECK(t.find_overlap(std::int64_t{B}, std::int64_t{B + 2'000'000}).has_value());
+    std::vector<I64> qs;
+    for (int i = 0; i < 200; ++i) {
+      const std::int64_t lo = B - 500'000 + (std::int64_t)rnd(3'000'000);
+      qs.emplace_back(lo, lo + (std::int64_t)rnd(5000));
+    }
+    auto b = t.find_overlaps_batch(qs);
+    CHECK_EQ(b.offsets.size(), qs.size() + 1);
+    bool batch_ok = true;
+    for (std::size_t i = 0; i < qs.size(); ++i) batch_ok = batch_ok && b.count(i) == brute(qs[i]).size();
+    CHECK(batch_ok);
+    // an insert BELOW the base moves the window
+    all.emplace_back(B - 40'000, B - 39'000);
+    t.insert_node(all.back().low, all.back().high);
+    CHECK(same(I64{B - 50'000, B + 10}));
+    CHECK(same(I64{B + 1000, B + 5000}));
+    // negative coordinates, unsigned 64-bit ones
+    IntervalTree<IntervalNode<I64>> neg{};
+    neg.insert_node(std::int64_t{-3'000'000'000'000}, std::int64_t{-2'999'999'999'000});
+    neg.insert_node(std::int64_t{-2'999'999'999'500}, std::int64_t{-2'999'999'000'000});
+    CHECK_EQ(neg.find_overlaps(std::int64_t{-2'999'999'999'400}, std::int64_t{-2'999'999'999'300}).size(), 2u);
+    CHECK_EQ(neg.find_overlaps(std::int64_t{-2'999'999'998'000}, std::int64_t{5}).size(), 1u);
+    IntervalTree<IntervalNode<U64>> u{};
+    u.insert_node(std::uint64_t{0xFFFFFFFFFFFF0000ull}, std::uint64_t{0xFFFFFFFFFFFF00FFull});
+    u.insert_node(std::uint64_t{0xFFFFFFFFFFFF0080ull}, std::uint64_t{0xFFFFFFFFFFFFFFFFull});
+    CHECK_EQ(u.find_overlaps(std::uint64_t{0xFFFFFFFFFFFF00F0ull}, std::uint64_t{0xFFFFFFFFFFFF0100ull}).size(), 2u);
+    CHECK_EQ(u.find_overlaps(std::uint64_t{0}, std::uint64_t{0xFFFFFFFFFFFEFFFFull}).size(), 0u);
+    // a span beyond 2^32 - 1: refused, loudly
+    IntervalTree<IntervalNode<I64>> wide{};
+    wide.insert_node(std::int64_t{0}, std::int64_t{10});
+    wide.insert_node(std::int64_t{5'000'000'000}, std::int64_t{5'000'000'010});
+    bool threw = false;
+    try {
+      (void)wide.find_overlaps(std::int64_t{0}, std::int64_t{20});
+    } catch (const std::domain_error &) {
+      threw = true;
+    }
+    CHECK(threw);
+    // the host tree (structure introspection) works for 64-bit keys as for 32-bit ones
+    CHECK(t.root() != nullptr && t.size(t.root()) == all.size());
+  }
   {  // empty tree
     IntervalTree<UIntIntervalNode> t{};
     CHECK(t.empty());

@@ -51,7 +51,7 @@ with IntervalIndex(0) as idx:
     st = idx.stats()
 b_alg = 34 * N
 ms = float(np.median(wall))
-print(json.dumps({"config": a.config, "intervals": N, "typed": bool(a.typed), "reps": a.reps,
+print(json.dumps({"commit": os.environ.get("BIVX_GIT_REV"), "config": a.config, "intervals": N, "typed": bool(a.typed), "reps": a.reps,
                   "build_ms_median": ms, "build_ms_min": float(np.min(wall)), "build_ms_max": float(np.max(wall)),
                   "intervals_per_s": N / ms * 1e3, "algorithmic_bytes": b_alg,
                   "roofline": {"bound": "hbm", "achieved_GBs": b_alg / ms / 1e6, "peak_GBs": 8000.0,

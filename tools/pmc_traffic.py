@@ -81,6 +81,7 @@ if len(sys.argv) > 3:  # the bench line of the same command: per-query and per-a
         out["rdreq_128B_per_query"] = rd128 / q
         out["l2_hit_rate"] = avg.get("TCC_HIT_sum", 0.0) / max(avg.get("TCC_HIT_sum", 0.0) + avg.get("TCC_MISS_sum", 0.0), 1.0)
         out["gpu_ms_per_step_unprofiled"] = b["roofline"]["gpu_ms_per_step"]
+        out["commit"] = b.get("commit")
     except Exception as e:
         out["bench_line_error"] = str(e)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
