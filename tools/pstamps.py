@@ -12,8 +12,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SORTED = "--sorted" in sys.argv
-subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "clean"])
-subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "-j8", "EXTRA=-DBIVX_STAMPS"])
+PREBUILT = bool(os.environ.get("BIVX_LIB"))   # a library built with -DBIVX_STAMPS by tools/build_variant.sh: nothing is compiled here
+if not PREBUILT:
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "clean"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "-j8", "EXTRA=-DBIVX_STAMPS"])
 os.environ["BIVX_PIPE"] = "2"
 from binary_amd import IntervalIndex, synth, capi  # noqa: E402
 
@@ -51,5 +53,6 @@ for a, b, nm in ((0, 1, "counting"), (1, 2, "wait for the next ticket + issue it
 dd = us[:, 4] - us[:, 0]
 dd = dd[(dd > 0) & (dd < 1000)]
 print(f"  whole iteration (worker 0): median {np.median(dd):6.2f}  p90 {np.percentile(dd, 90):6.2f}")
-subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "clean"])
-subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "-j8"])
+if not PREBUILT:
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "clean"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "binary_amd", "csrc"), "-s", "-j8"])
