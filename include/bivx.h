@@ -17,7 +17,11 @@
  *   - chrom ids partition the index: an interval and a query only meet when their chrom ids are equal
  *     (sv2nl builds one tree per chromosome, standalone/sv2nl/include/mapper.hpp:147-162,199);
  *     pass NULL chrom arrays for a single tree
- *   - calls taking `const bivx_index*` are thread-safe against each other; mutating calls are not
+ *   - calls taking `const bivx_index*` are thread-safe against each other; mutating calls are not. Host-pointer query
+ *     calls made from several threads on one index run side by side (each on a stream, an error block and a workspace of
+ *     its own: the reference shares one tree across its pool threads, mapper.cpp:127-142)
+ *   - bivx_build and bivx_clear wait for device-pointer calls that still read the index on caller streams; the caller
+ *     does not have to synchronise before it rebuilds
  *   - `_dev` entry points take DEVICE pointers and a hipStream_t (as void*; NULL = default stream) and
  *     never synchronise; the others take HOST pointers and return when the result is in host memory
  *   - there is no CPU fallback: without a usable gfx950 device bivx_create fails with BIVX_E_HIP
@@ -155,8 +159,9 @@ int bivx_get_intervals(const bivx_index *idx, const uint32_t *ids, size_t n, uin
  * replaces: IntervalTree::find_overlaps interval_tree.hpp:161-168,306-334, batched over q queries.
  * Result is CSR: offsets[q+1] (exclusive prefix of per-query hit counts, offsets[q] == total hits H)
  * and hit_ids[H]; query i's hits are hit_ids[offsets[i] .. offsets[i+1]).
- * Hit order inside one query: deterministic "index order" (ascending (length class, low, id)) straight
- * out of bivx_fill*, ascending id after bivx_sort_hits*. The reference returns RB-tree pre-order, a
+ * Hit order inside one query: deterministic "index order" straight out of bivx_fill* — ascending (length class,
+ * directory cell, id), or (length class, low, id) where the build sorted on every bit of low; do not rely on which —,
+ * ascending id after bivx_sort_hits* / with sort_by_id. The reference returns RB-tree pre-order, a
  * function of insertion history; as a SET the result is identical (tests compare sorted lists).
  *
  * Two calls because H is unknown a priori: count -> caller allocates hit_ids[H] -> fill. */
