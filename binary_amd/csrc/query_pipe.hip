@@ -55,6 +55,9 @@ constexpr uint32_t kRing = 8;                  // tile slots in LDS
 #ifndef BIVX_COOP_DEPTH
 #define BIVX_COOP_DEPTH 2   // rounds of coop_mask32 whose loads are in flight together (1: load, wait, evaluate; 2 fits 64 registers)
 #endif
+#ifndef BIVX_PLACE_DEPTH
+#define BIVX_PLACE_DEPTH 2   // rounds of coop_place16 whose loads are in flight together
+#endif
 #ifndef BIVX_EXP
 #define BIVX_EXP 0      // experiments (1, 2, 4: WRONG RESULTS, timing and instruction counts only): 1 no id layout, 2 no id stream-out, 4 no keep slots; 8: coop_mask32 instead of coop_place16 (same results)
 #endif
@@ -459,12 +462,24 @@ __device__ __forceinline__ uint32_t coop_place16(const uint2 *rec, uint32_t *out
     wpos += nh;                                                                                                       \
   }
 
-  {
+  {  // (BIVX_PLACE_DEPTH rounds' loads in flight: 2 by default)
+#if BIVX_PLACE_DEPTH == 4
+    BIVX_PLACE_LOAD(0) BIVX_PLACE_LOAD(1) BIVX_PLACE_LOAD(2) BIVX_PLACE_LOAD(3) BIVX_PLACE_EVAL(0)
+    BIVX_PLACE_LOAD(4) BIVX_PLACE_EVAL(1) BIVX_PLACE_LOAD(5) BIVX_PLACE_EVAL(2)
+    BIVX_PLACE_LOAD(6) BIVX_PLACE_EVAL(3) BIVX_PLACE_LOAD(7) BIVX_PLACE_EVAL(4)
+    BIVX_PLACE_EVAL(5) BIVX_PLACE_EVAL(6) BIVX_PLACE_EVAL(7)
+#elif BIVX_PLACE_DEPTH == 3
+    BIVX_PLACE_LOAD(0) BIVX_PLACE_LOAD(1) BIVX_PLACE_LOAD(2) BIVX_PLACE_EVAL(0)
+    BIVX_PLACE_LOAD(3) BIVX_PLACE_EVAL(1) BIVX_PLACE_LOAD(4) BIVX_PLACE_EVAL(2)
+    BIVX_PLACE_LOAD(5) BIVX_PLACE_EVAL(3) BIVX_PLACE_LOAD(6) BIVX_PLACE_EVAL(4)
+    BIVX_PLACE_LOAD(7) BIVX_PLACE_EVAL(5) BIVX_PLACE_EVAL(6) BIVX_PLACE_EVAL(7)
+#else
     BIVX_PLACE_LOAD(0) BIVX_PLACE_LOAD(1) BIVX_PLACE_EVAL(0)
     BIVX_PLACE_LOAD(2) BIVX_PLACE_EVAL(1) BIVX_PLACE_LOAD(3) BIVX_PLACE_EVAL(2)
     BIVX_PLACE_LOAD(4) BIVX_PLACE_EVAL(3) BIVX_PLACE_LOAD(5) BIVX_PLACE_EVAL(4)
     BIVX_PLACE_LOAD(6) BIVX_PLACE_EVAL(5) BIVX_PLACE_LOAD(7) BIVX_PLACE_EVAL(6)
     BIVX_PLACE_EVAL(7)
+#endif
   }
 #undef BIVX_PLACE_LOAD
 #undef BIVX_PLACE_EVAL
