@@ -55,6 +55,14 @@ struct bivx_index {
   DevBuf b_keys[2], b_ids[2];                 // sort buffers; the ids end up in one of b_ids and stay there (d_id)
   DevBuf b_misc, b_radix, b_scalar, b_segof;  // build temporaries: statistics, key tables, histogram scratch, maxima,
                                               // every interval's segment (two-sort builds)
+  // The statistics the build plans with, taken while the intervals come in (untyped appends): every append adds its
+  // intervals to this table — device-side appends by the very pass that copies them into the columns — so that
+  // bivx_build reads 120 MB less at 10 M intervals and an append of a few records to a large index does not pay for
+  // a pass over all of it. astats_n: intervals the table covers (== n: the build uses it).
+  DevBuf b_astats;
+  bool astats_ready = false;                  // emptied since creation / the last bivx_clear
+  size_t astats_n = 0;
+  hipEvent_t astats_ev = nullptr;             // the emptying, for appends on other streams to wait for
   uint32_t *h_scalars = nullptr;              // pinned: the build's few read-backs (max ids, largest cell)
   void *h_stage = nullptr;                    // pinned, grow-only: the statistics on their way down, the small tables
   size_t h_stage_cap = 0;                     // of the index on their way up
@@ -252,7 +260,7 @@ void free_built(bivx_index *idx) {
 
 void release_build_blocks(bivx_index *idx) {
   for (bivx_index::DevBuf *b : {&idx->b_se, &idx->b_table, &idx->b_seg, &idx->b_keys[0],
-                                &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof, &idx->b_selfq}) {
+                                &idx->b_keys[1], &idx->b_ids[0], &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof, &idx->b_selfq, &idx->b_astats}) {
     (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
@@ -384,6 +392,8 @@ int ensure_capacity(bivx_index *idx, size_t need) {
   return 0;
 }
 
+constexpr size_t kAppendStatsFrom = (size_t)4 << 20;  // intervals in an index's first append from which statistics ride on appends
+
 int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
                 const uint8_t *svtype, size_t n, hipMemcpyKind kind, hipStream_t s) {
   if (!idx || (n && (!low || !high))) {
@@ -402,12 +412,39 @@ int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, con
     }
   }
   BIVX_TRY(ensure_capacity(idx, idx->n + n));
-  if (chrom)
-    BIVX_HIP(hipMemcpyAsync(idx->d_chrom + idx->n, chrom, n * 4, kind, s));
-  else
-    BIVX_HIP(hipMemsetAsync(idx->d_chrom + idx->n, 0, n * 4, s));
-  BIVX_HIP(hipMemcpyAsync(idx->d_low + idx->n, low, n * 4, kind, s));
-  BIVX_HIP(hipMemcpyAsync(idx->d_high + idx->n, high, n * 4, kind, s));
+  // statistics ride on the append while the index has no interval types (see bivx_index::b_astats)
+  // (test knobs: BIVX_NO_APPEND_STATS = the build's own pass always; BIVX_APPEND_STATS_FROM = the first append's size from which)
+  const bool stats_at_append = !std::getenv("BIVX_NO_APPEND_STATS");
+  size_t stats_from = kAppendStatsFrom;
+  if (const char *e = std::getenv("BIVX_APPEND_STATS_FROM")) stats_from = (size_t)std::strtoull(e, nullptr, 10);
+  // (begun by a bulk append only: below a few million intervals the build's own pass is cheaper than the bookkeeping here —
+  // 1 M intervals: append + build 194 us with the pass in the build, 201 with it here; 50 M: 2.87 / 2.76 ms)
+  const bool with_stats = stats_at_append && !svtype && !idx->typed && idx->astats_n == idx->n &&
+                          (idx->astats_n != 0 || (idx->n == 0 && n >= stats_from));
+  if (with_stats && !idx->astats_ready) {
+    BIVX_TRY(ensure_block(idx->b_astats, auto_stats_bytes()));
+    if (!idx->astats_ev) BIVX_HIP(hipEventCreateWithFlags(&idx->astats_ev, hipEventDisableTiming));
+    BIVX_TRY(launch_init_auto_stats(idx->b_astats.p, idx->stream));
+    BIVX_HIP(hipEventRecord(idx->astats_ev, idx->stream));
+    idx->astats_ready = true;
+  }
+  if (with_stats && s != idx->stream) BIVX_HIP(hipStreamWaitEvent(s, idx->astats_ev, 0));
+  if (with_stats && kind == hipMemcpyDeviceToDevice) {
+    // one pass: the columns into the index, their statistics into the table
+    BIVX_TRY(launch_append_stats(chrom, low, high, n, idx->d_chrom + idx->n, idx->d_low + idx->n, idx->d_high + idx->n,
+                                 idx->b_astats.p, s));
+  } else {
+    if (chrom)
+      BIVX_HIP(hipMemcpyAsync(idx->d_chrom + idx->n, chrom, n * 4, kind, s));
+    else
+      BIVX_HIP(hipMemsetAsync(idx->d_chrom + idx->n, 0, n * 4, s));
+    BIVX_HIP(hipMemcpyAsync(idx->d_low + idx->n, low, n * 4, kind, s));
+    BIVX_HIP(hipMemcpyAsync(idx->d_high + idx->n, high, n * 4, kind, s));
+    if (with_stats)
+      BIVX_TRY(launch_append_stats(idx->d_chrom + idx->n, idx->d_low + idx->n, idx->d_high + idx->n, n, nullptr, nullptr, nullptr,
+                                   idx->b_astats.p, s));
+  }
+  if (with_stats) idx->astats_n += n;
   if (svtype) {
     BIVX_HIP(hipMemcpyAsync(idx->d_type + idx->n, svtype, n, kind, s));
     idx->typed = true;
@@ -759,7 +796,7 @@ size_t env_size(const char *name, size_t dflt) {
 size_t device_bytes_of(const bivx_index *idx) {
   size_t b = idx->cap * 13 + idx->cache_bytes + idx->b_selfq.cap;
   for (const bivx_index::DevBuf *d : {&idx->b_se, &idx->b_table, &idx->b_seg, &idx->b_keys[0], &idx->b_keys[1], &idx->b_ids[0],
-                                      &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof})
+                                      &idx->b_ids[1], &idx->b_misc, &idx->b_radix, &idx->b_scalar, &idx->b_segof, &idx->b_astats})
     b += d->cap;
   for (auto &kv : idx->ws_of_stream) b += fused_workspace_bytes(0) + kv.second.self_cap;
   return b;
@@ -787,6 +824,7 @@ void destroy_now(bivx_index *idx) {
   if (idx->h_stage) (void)hipHostFree(idx->h_stage);
   for (hipEvent_t ev : idx->ev_pending) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : idx->ev_free) (void)hipEventDestroy(ev);
+  if (idx->astats_ev) (void)hipEventDestroy(idx->astats_ev);
   (void)hipFree(idx->d_chrom);
   (void)hipFree(idx->d_low);
   (void)hipFree(idx->d_high);
@@ -819,6 +857,8 @@ bool park(bivx_index *idx) {
   free_built(idx);
   idx->n = 0;
   idx->typed = false;
+  idx->astats_n = 0;
+  idx->astats_ready = false;
   idx->built_n = 0;
   idx->build_ms = 0.0;
   idx->max_cell = idx->max_window = 0;
@@ -972,6 +1012,12 @@ int bivx_clear(bivx_index *idx) {
   BIVX_GUARD(idx);
   BIVX_HIP(hipStreamSynchronize(idx->stream));
   BIVX_TRY(wait_for_readers(idx));  // (the general self-overlap call reads the appended columns the next appends overwrite)
+  // appends still on their way on caller streams write the columns and the statistics table the next appends start over
+  for (hipEvent_t ev : idx->ev_pending) {
+    BIVX_HIP(hipEventSynchronize(ev));
+    idx->ev_free.push_back(ev);
+  }
+  idx->ev_pending.clear();
   free_built(idx);
   if (idx->typed && idx->d_type && idx->n) {
     // the slots are reused by later appends: an untyped append into them only clears type bytes while `typed` is set,
@@ -982,6 +1028,8 @@ int bivx_clear(bivx_index *idx) {
   }
   idx->n = 0;
   idx->typed = false;
+  idx->astats_n = 0;
+  idx->astats_ready = false;
   return 0;
 }
 
@@ -1032,9 +1080,15 @@ int bivx_build(bivx_index *idx) {
   bool have_stats = false;
   if (n && !idx->typed) {
     BIVX_TRY(ensure_stage(idx, auto_bytes));
-    BIVX_TRY(launch_bin_stats_auto(idx->d_chrom, idx->d_low, idx->d_high, n,
-                                   reinterpret_cast<BinStats *>(static_cast<char *>(idx->b_scalar.p) + 256), d_scalar, s));
-    BIVX_HIP(hipMemcpyAsync(idx->h_stage, d_scalar, auto_bytes, hipMemcpyDeviceToHost, s));
+    if (idx->astats_ready && idx->astats_n == n) {
+      // the appends left the statistics behind (their passes are ordered before this stream by the events above)
+      BIVX_HIP(hipMemsetAsync(d_scalar, 0, 16, s));  // (the build's own scalars: largest cell, the directory pass's list)
+      BIVX_HIP(hipMemcpyAsync(idx->h_stage, idx->b_astats.p, auto_bytes, hipMemcpyDeviceToHost, s));
+    } else {
+      BIVX_TRY(launch_bin_stats_auto(idx->d_chrom, idx->d_low, idx->d_high, n,
+                                     reinterpret_cast<BinStats *>(static_cast<char *>(idx->b_scalar.p) + 256), d_scalar, s));
+      BIVX_HIP(hipMemcpyAsync(idx->h_stage, d_scalar, auto_bytes, hipMemcpyDeviceToHost, s));
+    }
     BIVX_HIP(hipStreamSynchronize(s));
     max_chrom = static_cast<const uint32_t *>(idx->h_stage)[0];
     if (max_chrom == 0) {  // (no chromosome id beyond the pass's table: the largest is its last non-empty row)

@@ -133,6 +133,12 @@ int launch_bin_stats(const uint32_t *d_chrom, const uint8_t *d_type, uint32_t nt
 uint32_t bin_stats_auto_parts();
 int launch_bin_stats_auto(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n, BinStats *d_stats,
                           uint32_t *d_scal, hipStream_t s);
+// the index's own auto-form table ([4 scalars in 256 bytes | the entries]): emptied by launch_init_auto_stats, added to by
+// every untyped append — by the pass that copies the columns into the index when they come from device memory (d_out_*)
+size_t auto_stats_bytes();
+int launch_init_auto_stats(void *d_block, hipStream_t s);
+int launch_append_stats(const uint32_t *d_chrom, const uint32_t *d_low, const uint32_t *d_high, size_t n, uint32_t *d_out_chrom,
+                        uint32_t *d_out_low, uint32_t *d_out_high, void *d_block, hipStream_t s);
 // d_out2[0] = max chromosome id, d_out2[1] = max svtype (d_type may be nullptr); atomic maxima into words the caller zeroed
 int launch_max_chrom_type(const uint32_t *d_chrom, const uint8_t *d_type, size_t n, uint32_t *d_out2, hipStream_t s);
 // out[i] = src ? src[ids[i]] : 0 for ids[i] < n_src, else 0xFF

@@ -526,8 +526,8 @@ __device__ __forceinline__ void pipe_service_wave(kargs_t ka, TileSlot *s_slot, 
     // ---- a ticket ----
     if (drawing && drawn - swept < kRing) {
       bool want = drawn == 0;
-#ifdef BIVX_TICKET_EARLY   // experiment: a whole counting phase ahead (when every worker has begun the tile before)
-      if (!want) want = drawn == 1 || lds_load(&s_slot[(drawn - 2) % kRing].arrived) == (uint32_t)NW;
+#ifdef BIVX_TICKET_EARLY   // experiment: a counting phase ahead (when that many workers have begun the tile before; NW = all)
+      if (!want) want = drawn == 1 || lds_load(&s_slot[(drawn - 2) % kRing].arrived) >= (uint32_t)(BIVX_TICKET_EARLY);
 #else
       if (!want) want = lds_load(&s_slot[(drawn - 1) % kRing].arrived) != 0;
 #endif

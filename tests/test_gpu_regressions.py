@@ -490,3 +490,90 @@ def test_a_failed_call_is_reported_to_the_thread_that_made_it(oracle):
         # the index stays usable
         assert idx._L.bivx_count(idx._h, None, vp(big_lo), vp(big_hi), big_lo.size, vp(offs)) == 0
         assert np.array_equal(np.diff(offs.astype(np.int64)), oracle.count_overlaps_numpy(low, high, big_lo, big_hi))
+
+
+@pytest.mark.parametrize("max_chrom", [23, 64, 700])
+@pytest.mark.parametrize("device_appends", [False, True])
+def test_statistics_taken_by_the_appends_give_the_same_index(monkeypatch, max_chrom, device_appends):
+    """Untyped appends leave the build's (chromosome, length bin) statistics behind (capi.hip append_impl: device-side
+    appends copy and count in one pass; bivx_build then skips its own pass over the columns). Several appends — with and
+    without a chromosome column, from host and from device memory, a clear in between, ids beyond the one-pass table —
+    must give the index the build's own pass gives: same plan (segments, cells), same hits (interval_tree.hpp:306-328)."""
+    import torch
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(1000 + max_chrom)
+    n = 90_000
+    chrom = rng.integers(0, max_chrom + 1, n).astype(np.uint32)
+    chrom[: n // 3] = 0                                   # (the first append carries no chromosome column)
+    low = rng.integers(0, 300_000, n).astype(np.uint32)
+    high = (low + rng.integers(0, 4000, n) * (rng.random(n) < 0.9)).astype(np.uint32)
+    low[5], high[5] = 5000, 4000                          # an inverted interval: counted apart, same predicate
+    low[7], high[7] = 0, 0xFFFFFFFF                       # the longest there can be
+    cuts = [0, n // 3, n // 3 + 1, n // 3 + 4097, n]
+    q = 500
+    qc = rng.integers(0, max_chrom + 1, q).astype(np.uint32)
+    qlo = rng.integers(0, 300_000, q).astype(np.uint32)
+    qhi = (qlo + rng.integers(0, 6000, q)).astype(np.uint32)
+    exp = _brute(chrom, low, high, np.ones(n, bool), qc, qlo, qhi)
+
+    def fill(idx):
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            c = None if a == 0 else chrom[a:b]
+            if device_appends:
+                t = lambda x: torch.from_numpy(x.view(np.int32).copy()).cuda()
+                idx.insert_node(t(low[a:b]), t(high[a:b]), None if c is None else t(c))
+            else:
+                idx.insert_node(low[a:b], high[a:b], c)
+
+    got = {}
+    for mode in ("appends", "build"):
+        if mode == "appends":
+            monkeypatch.setenv("BIVX_APPEND_STATS_FROM", "1")
+            monkeypatch.delenv("BIVX_NO_APPEND_STATS", raising=False)
+        else:
+            monkeypatch.setenv("BIVX_NO_APPEND_STATS", "1")
+        with IntervalIndex(0) as idx:
+            idx.insert_node(low[:1000], high[:1000], chrom[:1000])   # something else first, thrown away again
+            idx.build()
+            idx.clear()
+            fill(idx)
+            idx.build()
+            st = idx.stats()
+            off, hits = idx.find_overlaps(qlo, qhi, qc)
+            _check_csr(off, hits, exp, True)
+            # more intervals after a build: the table goes on from where it was
+            idx.insert_node(low[:2000], high[:2000], chrom[:2000])
+            idx.build()
+            off2, hits2 = idx.find_overlaps(qlo, qhi, qc)
+            exp2 = [np.concatenate([e, n + x]) for e, x in
+                    zip(exp, _brute(chrom[:2000], low[:2000], high[:2000], np.ones(2000, bool), qc, qlo, qhi))]
+            _check_csr(off2, hits2, exp2, True)
+            got[mode] = (st["n_segments"], st["n_cells"], st["n_chroms"], off.copy(), hits.copy())
+    a, b = got["appends"], got["build"]
+    assert a[:3] == b[:3]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_typed_append_after_untyped_ones_drops_the_appends_statistics(monkeypatch):
+    """The appends' statistics table has no interval types: an index that turns typed is planned by the build's own passes."""
+    from binary_amd import IntervalIndex
+    monkeypatch.setenv("BIVX_APPEND_STATS_FROM", "1")
+    rng = np.random.default_rng(77)
+    n = 30_000
+    chrom = rng.integers(0, 5, n).astype(np.uint32)
+    low = rng.integers(0, 100_000, n).astype(np.uint32)
+    high = (low + rng.integers(0, 2000, n)).astype(np.uint32)
+    typ = rng.integers(1, 4, n).astype(np.uint8)
+    typ[: n // 2] = 0
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low[: n // 2], high[: n // 2], chrom[: n // 2])
+        idx.insert_node(low[n // 2:], high[n // 2:], chrom[n // 2:], svtype=typ[n // 2:])
+        idx.build()
+        q = 300
+        qc = rng.integers(0, 5, q).astype(np.uint32)
+        qlo = rng.integers(0, 100_000, q).astype(np.uint32)
+        qhi = (qlo + rng.integers(0, 3000, q)).astype(np.uint32)
+        off, hits = idx.find_overlaps(qlo, qhi, qc)
+        _check_csr(off, hits, _brute(chrom, low, high, np.ones(n, bool), qc, qlo, qhi), True)
+        off, hits = idx.find_overlaps(qlo, qhi, qc, svtype=2)
+        _check_csr(off, hits, _brute(chrom, low, high, typ == 2, qc, qlo, qhi), True)
