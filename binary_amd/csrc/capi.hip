@@ -572,6 +572,9 @@ int plan_classes(const std::vector<BinStats> &st, uint32_t nchrom, size_t n_tota
       table_off += (uint64_t)d.ncell + 1;
       begin += cnt;
       if (mx > plan.max_low) plan.max_low = mx;
+      if (std::getenv("BIVX_PLAN_DEBUG"))  // (stderr: what the planner made of the statistics)
+        std::fprintf(stderr, "[bivx plan] partition %u class %d: %llu intervals, max length %u, lows %u..%u, cell 2^%u, %u cells%s\n",
+                     c, ns - 1 - k, (unsigned long long)cnt, ml, mn, mx, sh, d.ncell, (d.shift & kSegPacked) ? ", packed" : "");
       plan.segs.push_back(d);
     }
   }

@@ -1382,6 +1382,15 @@ constexpr uint32_t kMsKeepWords = kMsKeepN * kWave;              // ... a wavefr
 constexpr uint32_t kMsBuf = 448;      // ids a wavefront lines up per round on their way out
 static_assert(kMsBuf >= 6 * kWave, "the walk's table of window words lives in the buffer");
 constexpr uint32_t kMsStage = 2 * kMsKeepWords + kMsBuf;         // a wavefront's LDS: two pending slices' keep slots + the buffer
+#ifndef BIVX_MS_OWN
+#define BIVX_MS_OWN 48
+#endif
+#ifndef BIVX_MS_OWN_TRIP
+#define BIVX_MS_OWN_TRIP 16
+#endif
+constexpr uint32_t kMsOwnTrip = BIVX_MS_OWN_TRIP;                // slots of its own window a lane evaluates per trip
+constexpr uint32_t kMsOwnSlots = BIVX_MS_OWN;                    // a segment whose windows all end within that many slots of their
+                                                                 // first even slot: every lane evaluates its own (0: never)
 constexpr uint32_t kMsGroupMax = 1024;                           // slots of the longest window a group of lanes walks
 
 // Every lane's hits over all its segments, in index order (segment, slot), by GROUPS of eight lanes, as coop_mask32 does it
@@ -1474,6 +1483,58 @@ __device__ __forceinline__ uint32_t group_scan(kargs_t ka, const SegDesc *segs, 
     if (MODE != kMsEmit && __any(n > kMsGroupMax)) {
       too_long = true;
       return 0u;
+    }
+    if (kMsOwnSlots != 0 && STORE && !__any(n > kMsOwnSlots)) {
+      // Every window of this segment is short (the short classes of an SV-like spectrum: a handful of slots each, 9 and 15 on
+      // average in tools/skewed_bench.py 1e4): each lane evaluates its own, kMsOwnTrip slots per trip — that many / 2 16-byte
+      // loads in flight —, no table, no ballots, its hits in slot order straight to its list. (Eight lanes per window make a
+      // round of eight steps of sixteen slots, ~45 vector instructions a step, whatever the windows hold.) Only when ids are
+      // stored: what it saves is their ranking among the group's hits and the owner's place travelling through ds_swizzle —
+      // a walk that only counts is faster in groups. tools/skewed_bench.py 1e4 / 1e5 / 1e6, single pass, by kMsOwnSlots:
+      // 0: 0.139 / 0.495 / 2.29 ms   24: 0.128 / 0.497 / 2.32   48: 0.124 / 0.498 / 2.33   64: 0.126 / 0.568 / 2.75   128: 0.126 / 0.907 / 3.08
+      const uint32_t sub = w.packed ? w.cell0 : 0u;
+      const uint32_t qh = q.hi - sub, ql = q.lo > sub ? q.lo - sub : 0u;
+      const uint32_t smsk = w.packed ? 0xFFFFu : 0xFFFFFFFFu;
+      for (uint32_t c0 = 0; __any(c0 < n); c0 += kMsOwnTrip) {
+        const uint32_t off = ((al + c0) >> 1) << 4;
+        uint4 r[kMsOwnTrip / 2];
+        uint2 ip[kMsOwnTrip / 2];
+#pragma unroll
+        for (uint32_t j = 0; j < kMsOwnTrip / 2; ++j) {
+          asm volatile("" : "=v"(r[j].x), "=v"(r[j].y), "=v"(r[j].z), "=v"(r[j].w));  // (no value: masked below)
+          asm volatile("" : "=v"(ip[j].x), "=v"(ip[j].y));
+          if (c0 + 2u * j < n) {
+            r[j] = *reinterpret_cast<const uint4 *>(se_b + (off + 16u * j + (w.packed ? rec_delta : 0u)));
+            if (EMIT && !w.packed) ip[j] = *reinterpret_cast<const uint2 *>(id_b + ((off + 16u * j) >> 1));
+          }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kMsOwnTrip / 2; ++j) {
+          const uint32_t s2 = c0 + 2u * j;
+          const uint32_t la = (r[j].x - sub) & smsk, lb = (r[j].z - sub) & smsk;
+          const uint32_t ha = w.packed ? la + (r[j].x >> 16) : r[j].y, hb = w.packed ? lb + (r[j].z >> 16) : r[j].w;
+          const uint32_t ida = w.packed ? r[j].y : ip[j].x, idb = w.packed ? r[j].w : ip[j].y;
+          bool fa = s2 < n && (s2 != 0u || (w.a & 1u) == 0u) && la <= qh && ha >= ql;
+          bool fb = s2 + 1u < n && lb <= qh && hb >= ql;
+          if (F) {
+            if (fa) fa = filter_accept(fv, q.lo, q.hi, q.aux, la + sub, ha + sub, ida);
+            if (fb) fb = filter_accept(fv, q.lo, q.hi, q.aux, lb + sub, hb + sub, idb);
+          }
+          if (STORE) {
+            const uint32_t atA = lpos + acc, atB = atA + (fa ? 1u : 0u);
+            if (MODE == kMsKeep) {
+              if (fa && atA < kMsKeepN) stage[(atA << 6) | lane] = ida;
+              if (fb && atB < kMsKeepN) stage[(atB << 6) | lane] = idb;
+            } else {
+              char *const ob = reinterpret_cast<char *>(stage);
+              if (BIVX_EXP_STORE(fa && atA < limit)) *reinterpret_cast<uint32_t *>(ob + (atA << 2)) = ida;
+              if (BIVX_EXP_STORE(fb && atB < limit)) *reinterpret_cast<uint32_t *>(ob + (atB << 2)) = idb;
+            }
+          }
+          acc += (fa ? 1u : 0u) + (fb ? 1u : 0u);
+        }
+      }
+      continue;
     }
     {
       const uint32_t sub = w.packed ? w.cell0 : 0u;

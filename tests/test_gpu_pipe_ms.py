@@ -227,3 +227,51 @@ def test_many_ids_per_query_on_one_length_class(oracle, order):
             off_f, hits_f = _run(idx, 0, dq, dqh, None, H, by_id)
             assert np.array_equal(off_p, off_f) and np.array_equal(hits_p[:H], hits_f[:H]), by_id
     assert np.array_equal(np.diff(off_p), oracle.count_overlaps_numpy(low, high, low, high))
+
+
+@pytest.mark.parametrize("many", [False, True])
+def test_short_windows_in_packed_and_plain_classes(many):
+    """Segments whose 64 windows all end within 48 slots are evaluated lane by lane (group_scan's own-window trips: 16 slots
+    per trip, windows that begin at odd slots, a second and third trip), in classes that store 16 + 16-bit records and in a
+    class that does not (lengths beyond 65 535: ids from id[]). `many`: piles that put some lists beyond the sixteen keep slots,
+    so that slices are walked again with the ids going straight to the output. Against k_query_fused bit for bit and against
+    the predicate (interval_tree.hpp:119-121)."""
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(31 + many)
+    n = 120_000
+    low = rng.integers(0, G - 2_000_000, size=n).astype(np.uint32)
+    ln = np.where(rng.random(n) < 0.7, rng.integers(50, 3000, n), rng.integers(70_000, 900_000, n))
+    if many:  # forty piles of 30 short intervals each: lists of 30+ ids for the queries that fall there
+        at = rng.integers(0, G - 2_000_000, size=40)
+        low[:1200] = (at[:, None] + rng.integers(0, 40, (40, 30))).ravel()
+        ln[:1200] = 500
+    high = (low + ln).astype(np.uint32)
+    q = 60_000
+    qlo = rng.integers(0, G, size=q).astype(np.uint32)
+    if many:
+        qlo[:4000] = (at[rng.integers(0, 40, 4000)] + rng.integers(0, 300, 4000)).astype(np.uint32)
+        qlo = qlo[rng.permutation(q)]
+    qhi = (qlo + rng.integers(0, 2000, q) * (rng.random(q) < 0.5)).astype(np.uint32)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        assert idx.stats()["n_segments"] >= 2
+        dq, dqh = _to(qlo), _to(qhi)
+        H = int(idx.count_overlaps_device(dq, dqh)[-1].item())
+        with _env(BIVX_PIPE=2):
+            assert idx.query_kernel_name(q, H, False) == "k_query_pipe_ms"
+        for by_id in (False, True):
+            off_p, hits_p = _run(idx, 2, dq, dqh, None, H, by_id)
+            off_f, hits_f = _run(idx, 0, dq, dqh, None, H, by_id)
+            assert np.array_equal(off_p, off_f) and int(off_p[-1]) == H
+            assert np.array_equal(hits_p[:H], hits_f[:H]), by_id
+        cnt = np.diff(off_p)
+        if many:
+            assert cnt.max() > 16
+        for k in np.r_[np.argsort(cnt)[-20:], np.arange(0, q, q // 200)]:
+            exp = np.flatnonzero((low <= qhi[k]) & (high >= qlo[k]))
+            assert np.array_equal(hits_p[off_p[k]:off_p[k + 1]], exp), k
+        cap = H // 2   # a buffer smaller than the result (index order): the ids up to the capacity as before, nothing beyond
+        off_i, hits_i = _run(idx, 2, dq, dqh, None, H, False)
+        off_c, hits_c = _run(idx, 2, dq, dqh, None, H, False, cap=cap)
+        assert np.array_equal(off_c, off_i) and np.array_equal(hits_c[:cap], hits_i[:cap])
