@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
 constexpr int kMsThreads = 512;
 constexpr int kMsWorkers = kMsThreads / kWave - 1;
 constexpr uint32_t kMsTile = kMsWorkers * kWave;
-constexpr uint32_t kMsKeepN = 16;                                // ids a lane keeps while its slice is pending
+constexpr uint32_t kMsKeepN = 16;                                // ids a lane keeps while its slice is pending — on average: see ms_keep_word
 #ifdef BIVX_MS_NOKEEP
 constexpr uint32_t kMsKeepWords = 0;
 #else
@@ -1416,8 +1416,18 @@ __device__ __forceinline__ uint32_t of_group_lane(uint32_t x) {  // the value of
   return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x18 | (J << 5));
 }
 
-// MODE: kMsCount — the counts alone; kMsKeep — the counts, and the first kMsKeepN ids of every lane go to its keep slots
-// (`stage`: the wavefront's 64 x kMsKeepN words, slot i of lane l at word i * 64 + l); kMsEmit — the ids go to
+// The keep slots of a wavefront are 64 x kMsKeepN words, and two neighbouring lanes SHARE their 2 x kMsKeepN: the even lane
+// fills them from the bottom, the odd lane from the top, so a slice is kept whenever no PAIR has more than 32 ids — with 7.6 ids
+// per query 18 % of the slices have a lane beyond 16, 1 % a pair beyond 32, and every slice that is not kept is walked twice.
+// (Where the two lists would meet, one overwrites the other: such a slice is not kept, nobody reads its slots.)
+// Pair slot t of the pair (2p, 2p + 1) is word (t / 2) * 64 + 2p + t % 2.
+__device__ __forceinline__ uint32_t ms_keep_word(uint32_t i, uint32_t lane) {
+  const uint32_t t = (lane & 1u) ? 2u * kMsKeepN - 1u - i : i;
+  return ((t >> 1) << 6) | (lane & ~1u) | (t & 1u);
+}
+
+// MODE: kMsCount — the counts alone; kMsKeep — the counts, and every lane's first ids go to its pair's keep slots (`stage`:
+// the wavefront's 64 x kMsKeepN words, ms_keep_word; at most 2 x kMsKeepN per lane are written); kMsEmit — the ids go to
 // stage[lpos ..) (the output itself; positions from `limit` on are not written).
 constexpr int kMsCount = 0, kMsKeep = 1, kMsEmit = 2;
 #ifdef BIVX_EXP_NOSTORE  // experiment (wrong results): the second walk without its stores
@@ -1529,8 +1539,8 @@ __device__ __forceinline__ uint32_t group_scan(kargs_t ka, const SegDesc *segs, 
           if (STORE) {
             const uint32_t atA = lpos + acc, atB = atA + (fa ? 1u : 0u);
             if (MODE == kMsKeep) {
-              if (fa && atA < kMsKeepN) stage[(atA << 6) | lane] = ida;
-              if (fb && atB < kMsKeepN) stage[(atB << 6) | lane] = idb;
+              if (fa && atA < 2u * kMsKeepN) stage[ms_keep_word(atA, lane)] = ida;
+              if (fb && atB < 2u * kMsKeepN) stage[ms_keep_word(atB, lane)] = idb;
             } else {
               char *const ob = reinterpret_cast<char *>(stage);
               if (BIVX_EXP_STORE(fa && atA < limit)) *reinterpret_cast<uint32_t *>(ob + (atA << 2)) = ida;
@@ -1596,8 +1606,8 @@ __device__ __forceinline__ uint32_t group_scan(kargs_t ka, const SegDesc *segs, 
       const uint32_t mineA = (bA >> p) & 1u, mineB = (bB >> p) & 1u;                                           \
       const uint32_t at = spos + (uint32_t)__popc(bA & below) + (uint32_t)__popc(bB & below);                  \
       if (MODE == kMsKeep) {                                                                                   \
-        if (mineA && at < kMsKeepN) stage[(at << 6) | gsh | (J)] = ida;                                        \
-        if (mineB && at + mineA < kMsKeepN) stage[((at + mineA) << 6) | gsh | (J)] = idb;                      \
+        if (mineA && at < 2u * kMsKeepN) stage[ms_keep_word(at, gsh | (J))] = ida;                             \
+        if (mineB && at + mineA < 2u * kMsKeepN) stage[ms_keep_word(at + mineA, gsh | (J))] = idb;             \
       } else { /* (a slice has fewer than 2^28 ids: 32-bit byte offsets from the slice's first output position) */ \
         char *const ob = reinterpret_cast<char *>(stage);                                                      \
         if (BIVX_EXP_STORE(mineA && at < limit)) *reinterpret_cast<uint32_t *>(ob + (at << 2)) = ida;          \
@@ -1712,12 +1722,12 @@ __global__ __launch_bounds__(kMsThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Ind
       const uint32_t room = cap > wp ? (cap - wp < 0xFFFFFFFFull ? (uint32_t)(cap - wp) : 0xFFFFFFFFu) : 0u;
       if (pd.kept) {
         // out of the keep slots: kMsBuf ids at a time are lined up as they sit in the output and leave in whole lines
-        const uint32_t *const keep = s_stage[wave] + (j & 1u) * kMsKeepWords + lane;
+        const uint32_t *const keep = s_stage[wave] + (j & 1u) * kMsKeepWords;
         uint32_t *const buf = s_stage[wave] + 2 * kMsKeepWords;
         for (uint32_t r0 = 0; r0 < pd.wtotal; r0 += kMsBuf) {
           const uint32_t i0 = r0 > loff ? r0 - loff : 0u;                                         // the lane's ids i0 .. i1-1 are in
           const uint32_t i1 = r0 + kMsBuf < loff + pd.cnt ? (r0 + kMsBuf > loff ? r0 + kMsBuf - loff : 0u) : pd.cnt;  // this round
-          for (uint32_t i = i0; i < i1; ++i) buf[loff + i - r0] = keep[i << 6];
+          for (uint32_t i = i0; i < i1; ++i) buf[loff + i - r0] = keep[ms_keep_word(i, (uint32_t)lane)];
           wave_sync_lds();
           const uint32_t nthis = pd.wtotal - r0 < kMsBuf ? pd.wtotal - r0 : kMsBuf;
           const uint32_t lim = room > r0 ? (room - r0 < nthis ? room - r0 : nthis) : 0u;
@@ -1792,7 +1802,9 @@ __global__ __launch_bounds__(kMsThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Ind
     // (2^22 hits in one lane would overflow the 32-bit scan: such a slice is summed in 64 bits and left to k_fill_slices)
     const bool huge = __any(cnt >= (1u << 22));
     const bool general = too_long || huge;
-    const bool fits = !general && !__any(cnt > kMsKeepN);
+    // (kept: no pair of neighbouring lanes has more ids than the pair's keep slots)
+    const uint32_t pair_cnt = cnt + (uint32_t)__builtin_amdgcn_ds_swizzle((int)cnt, 0x041F);  // (xor 1: the neighbour's count)
+    const bool fits = !general && !__any(pair_cnt > 2u * kMsKeepN);
     const bool kept = fits && !no_ids;
 #ifndef BIVX_MS_NOKEEP
     // (two slices in a row with a list beyond the keep slots before the first walk stops keeping ids: with 7.6 ids per query
