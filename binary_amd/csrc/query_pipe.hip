@@ -1373,7 +1373,11 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
 constexpr int kMsThreads = 512;
 constexpr int kMsWorkers = kMsThreads / kWave - 1;
 constexpr uint32_t kMsTile = kMsWorkers * kWave;
-constexpr uint32_t kMsKeepN = 16;                                // ids a lane keeps while its slice is pending — on average: see ms_keep_word
+#ifndef BIVX_MS_DEFER
+#define BIVX_MS_DEFER 2   // iterations a counted slice waits for its place in the output (1: experiment — one pending slice, twice the keep slots)
+#endif
+constexpr uint32_t kMsDefer = BIVX_MS_DEFER;
+constexpr uint32_t kMsKeepN = 32 / kMsDefer;                     // ids a lane keeps while its slice is pending — on average: see ms_keep_word
 #ifdef BIVX_MS_NOKEEP
 constexpr uint32_t kMsKeepWords = 0;
 #else
@@ -1387,7 +1391,7 @@ constexpr uint32_t kMsKeepWords = kMsKeepN * kWave;              // ... a wavefr
 #endif
 constexpr uint32_t kMsBuf = BIVX_MS_BUF;      // ids a wavefront lines up per round on their way out
 static_assert(kMsBuf >= 6 * kWave, "the walk's table of window words lives in the buffer");
-constexpr uint32_t kMsStage = 2 * kMsKeepWords + kMsBuf;         // a wavefront's LDS: two pending slices' keep slots + the buffer
+constexpr uint32_t kMsStage = kMsDefer * kMsKeepWords + kMsBuf;  // a wavefront's LDS: the pending slices' keep slots + the buffer
 #ifndef BIVX_MS_OWN
 #define BIVX_MS_OWN 48
 #endif
@@ -1722,8 +1726,8 @@ __global__ __launch_bounds__(kMsThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Ind
       const uint32_t room = cap > wp ? (cap - wp < 0xFFFFFFFFull ? (uint32_t)(cap - wp) : 0xFFFFFFFFu) : 0u;
       if (pd.kept) {
         // out of the keep slots: kMsBuf ids at a time are lined up as they sit in the output and leave in whole lines
-        const uint32_t *const keep = s_stage[wave] + (j & 1u) * kMsKeepWords;
-        uint32_t *const buf = s_stage[wave] + 2 * kMsKeepWords;
+        const uint32_t *const keep = s_stage[wave] + (kMsDefer == 2 ? (j & 1u) * kMsKeepWords : 0u);
+        uint32_t *const buf = s_stage[wave] + kMsDefer * kMsKeepWords;
         for (uint32_t r0 = 0; r0 < pd.wtotal; r0 += kMsBuf) {
           const uint32_t i0 = r0 > loff ? r0 - loff : 0u;                                         // the lane's ids i0 .. i1-1 are in
           const uint32_t i1 = r0 + kMsBuf < loff + pd.cnt ? (r0 + kMsBuf > loff ? r0 + kMsBuf - loff : 0u) : pd.cnt;  // this round
@@ -1740,7 +1744,7 @@ __global__ __launch_bounds__(kMsThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Ind
         const Query qy = query_of(pd.tile);
         bool dummy;
         (void)group_scan<kMsEmit, F>(ka, segs, qy, pd.cnt != 0, out, loff, room, (uint32_t)lane,
-                                     s_stage[wave] + 2 * kMsKeepWords, dummy);
+                                     s_stage[wave] + kMsDefer * kMsKeepWords, dummy);
       }
     }
     if (lane == 0) __hip_atomic_fetch_add(&os.flushed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1759,10 +1763,15 @@ __global__ __launch_bounds__(kMsThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Ind
   for (uint32_t it = 0;; ++it) {
     const bool live = tile < A(ntiles);
     // the slice counted two iterations ago goes out FIRST: its keep slots are the ones this iteration's slice fills
-    if (pb.have) flush(pb, it - 2);
-    if (!live) {
+    if (kMsDefer == 2) {
+      if (pb.have) flush(pb, it - 2);
+      if (!live) {
+        if (pa.have) flush(pa, it - 1);
+        break;
+      }
+    } else {
       if (pa.have) flush(pa, it - 1);
-      break;
+      if (!live) break;
     }
     bool too_long;
     uint32_t cnt;
@@ -1770,10 +1779,10 @@ __global__ __launch_bounds__(kMsThreads, BIVX_MS_WAVES) void k_query_pipe_ms(Ind
     // every slice is walked a second time anyway and the first walk need not store anything)
     const bool no_ids = A(cap) == 0 || !keep_mode;
     if (no_ids)
-      cnt = group_scan<kMsCount, F>(ka, segs, qy, true, nullptr, 0u, 0u, (uint32_t)lane, s_stage[wave] + 2 * kMsKeepWords, too_long);
+      cnt = group_scan<kMsCount, F>(ka, segs, qy, true, nullptr, 0u, 0u, (uint32_t)lane, s_stage[wave] + kMsDefer * kMsKeepWords, too_long);
     else
-      cnt = group_scan<kMsKeep, F>(ka, segs, qy, true, s_stage[wave] + (it & 1u) * kMsKeepWords, 0u, 0u, (uint32_t)lane,
-                                   s_stage[wave] + 2 * kMsKeepWords, too_long);
+      cnt = group_scan<kMsKeep, F>(ka, segs, qy, true, s_stage[wave] + (kMsDefer == 2 ? (it & 1u) * kMsKeepWords : 0u), 0u, 0u, (uint32_t)lane,
+                                   s_stage[wave] + kMsDefer * kMsKeepWords, too_long);
     if (too_long) {
       kargs_t p = fresh(ka);
       IndexView v1;
