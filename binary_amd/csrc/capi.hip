@@ -1483,11 +1483,16 @@ int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_of
   }
   const uint32_t *q = static_cast<const uint32_t *>(idx->b_selfq.p);
   void *ws = nullptr, *self_p = nullptr;
-  // per stream: [counts u32 x n | scan scratch | list sources u64 x n | the lists in slot order u32 x capacity]
-  const size_t cnt_bytes = (n * 4 + 255) & ~(size_t)255, scan_bytes = (scan_scratch_bytes(n) + 255) & ~(size_t)255;
-  const size_t src_bytes = hit_capacity ? (n * 8 + 255) & ~(size_t)255 : 0;
-  // (+ 256: k_permute_lines reads the lists in whole aligned lines, the last one may reach past the last id)
-  const size_t self_bytes = cnt_bytes + scan_bytes + src_bytes + (size_t)hit_capacity * 4 + 256;
+  // per stream: [scan scratch | per id: list length << kSelfPosBits | where it begins, u64 x n | the lists in slot order]
+  const size_t scan_bytes = (scan_scratch_bytes(n) + 255) & ~(size_t)255;
+  const size_t src_bytes = (n * 8 + 255) & ~(size_t)255;
+  // (+ 64 ids: k_permute_lines reads the lists in whole aligned lines, the last one may reach past the last id)
+  const uint64_t tmp_cap = hit_capacity ? hit_capacity + 64 : 0;
+  if (tmp_cap > kSelfPosMask) {
+    set_error("bivx_self_overlaps_dev: a hit capacity beyond 2^38 ids");
+    return BIVX_E_RANGE;
+  }
+  const size_t self_bytes = scan_bytes + src_bytes + (size_t)tmp_cap * 4;
   {
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     auto it = idx->ws_of_stream.find(s);
@@ -1524,15 +1529,14 @@ int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_of
     self_p = it->second.self_p;
   }
   char *base = static_cast<char *>(self_p);
-  uint32_t *d_counts = reinterpret_cast<uint32_t *>(base);
-  void *scan_scr = base + cnt_bytes;
-  uint64_t *d_src = reinterpret_cast<uint64_t *>(base + cnt_bytes + scan_bytes);
-  uint32_t *d_tmp = reinterpret_cast<uint32_t *>(base + cnt_bytes + scan_bytes + src_bytes);
-  // one pass in slot order (lists back to back in d_tmp; per id the list's length and where it begins), offsets = a scan of
-  // the lengths, then the lists are gathered into id order
-  BIVX_TRY(launch_self_overlaps(view, q, q + n, q + 2 * n, idx->d_id, n, d_counts, hit_capacity ? d_src : nullptr, d_offsets,
-                                hit_capacity ? d_tmp : nullptr, hit_capacity, static_cast<uint64_t *>(ws), true, s));
-  BIVX_TRY(exclusive_scan_u32_u64(d_counts, d_offsets, n, scan_scr, s));
+  void *scan_scr = base;
+  uint64_t *d_src = reinterpret_cast<uint64_t *>(base + scan_bytes);
+  uint32_t *d_tmp = reinterpret_cast<uint32_t *>(base + scan_bytes + src_bytes);
+  // one pass in slot order (lists back to back in d_tmp; per id ONE word: the list's length above where it begins), offsets =
+  // a scan of the lengths, then the lists are gathered into id order
+  BIVX_TRY(launch_self_overlaps(view, q, q + n, q + 2 * n, idx->d_id, n, d_src, d_offsets, hit_capacity ? d_tmp : nullptr,
+                                hit_capacity, static_cast<uint64_t *>(ws), true, s));
+  BIVX_TRY(exclusive_scan_lengths_u64(d_src, d_offsets, n, scan_scr, s));
   if (hit_capacity) {
     bool sorted = false;  // (the line-wise gather orders the lists while they pass through LDS)
     BIVX_TRY(launch_permute_lists(d_offsets, d_src, d_tmp, d_hit_ids, n, hit_capacity, sort_by_id != 0, &sorted, s));

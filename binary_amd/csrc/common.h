@@ -123,6 +123,11 @@ int sharded_query_dev(const ShardedState *st, const uint32_t *qchrom, const uint
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = total. scratch: scan_scratch_bytes(n).
 size_t scan_scratch_bytes(size_t n);
 int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s);
+// bivx_self_overlaps_dev keeps, per id, ONE word: the list's length above the 38-bit position where it begins in the scratch
+// (2^38 ids are 1.1 TB; a launch has fewer than 2^26 queries, so a length fits the 26 bits above)
+constexpr int kSelfPosBits = 38;
+constexpr uint64_t kSelfPosMask = (1ull << kSelfPosBits) - 1ull;
+int exclusive_scan_lengths_u64(const uint64_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s);
 
 // ---- build.hip --------------------------------------------------------------------------------------
 // the partition of interval i is chrom[i] * ntypes + type[i] (type == nullptr: chrom[i])
@@ -207,11 +212,11 @@ int launch_query_pipe_ms(const IndexView &v, const uint32_t *d_qchrom, const uin
                          size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
                          int flags, uint32_t skip_seq, hipStream_t s);
 // The index overlapped with itself (queries = its intervals in slot order, results wanted in id order: d_perm = the slots'
-// ids): k_query_pipe_dense writes the lists in slot order into d_tmp_hits and leaves d_counts[id] / d_src_by_id[id] = a
-// list's length / where it begins (cap == 0: the lengths only); launch_permute_lists then gathers list i to d_hits[offsets[i]].
+// ids): k_query_pipe_dense writes the lists in slot order into d_tmp_hits and leaves d_src_by_id[id] = a list's length <<
+// kSelfPosBits | where it begins (cap == 0: the lengths only); launch_permute_lists then gathers list i to d_hits[offsets[i]].
 bool self_overlaps_eligible(const IndexView &v, size_t n);
 int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
-                         const uint32_t *d_perm, size_t n, uint32_t *d_counts, uint64_t *d_src_by_id,
+                         const uint32_t *d_perm, size_t n, uint64_t *d_src_by_id,
                          uint64_t *d_offsets_scratch, uint32_t *d_tmp_hits, uint64_t cap, uint64_t *ws, bool self_clean,
                          hipStream_t s);
 int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,

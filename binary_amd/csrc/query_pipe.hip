@@ -107,11 +107,11 @@ struct PipeArgs {
   // Results wanted in ANOTHER order than the queries' (bivx_self_overlaps_dev: the queries are the index's own intervals
   // in slot order, the CSR is wanted in id order; k_query_pipe_dense and k_fill_slices only). perm[q] = the query's
   // position in the result. The ids are written as always — the batch's lists back to back, in the queries' order — but
-  // instead of offsets[q] the kernel leaves dst_counts[perm[q]] = the query's number of ids and src_by_id[perm[q]] = where
-  // its list begins; k_permute_lists then moves the lists into the result's order.
+  // instead of offsets[q] the kernel leaves src_by_id[perm[q]] = the query's number of ids << kSelfPosBits | where its list
+  // begins (one scattered store per query); k_permute_lists then moves the lists into the result's order.
   const uint32_t *perm;
   uint64_t *src_by_id;
-  uint32_t *dst_counts;
+  uint32_t *unused_;
   uint32_t rec_delta;  // k_query_pipe_ms: byte distance from se[] to rec[] (one block, below 4 GB)
   uint32_t tile_q;     // queries per tile of the kernel that listed slices for k_fill_slices (960; k_query_pipe_ms: 448)
 };
@@ -1174,9 +1174,8 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
       const uint32_t loff = pd.st >> 15, cnt = pd.st & 127u;
       if (q < q_end) {
         if (perm) {  // (bivx_self_overlaps_dev: count and list position go where the query's id says)
-          const uint32_t dst = perm[q];
-          p->a.dst_counts[dst] = cnt;
-          if (cap != 0) p->a.src_by_id[dst] = wpos0 + loff;
+          // (ONE scattered 8-byte store per interval: the list's length above the position where it begins)
+          p->a.src_by_id[perm[q]] = (uint64_t)cnt << kSelfPosBits | (cap != 0 ? wpos0 + loff : 0ull);
         } else {
           stream_store(off + q, wpos0 + loff);
           if (q == q_end - 1) off[q_end] = wpos0 + loff + cnt;
@@ -1223,9 +1222,7 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
     } else {
       if (q < q_end) {
         if (perm) {
-          const uint32_t dst = perm[q];
-          p->a.dst_counts[dst] = pd.st;
-          if (cap != 0) p->a.src_by_id[dst] = wpos0 + pd.x;
+          p->a.src_by_id[perm[q]] = (uint64_t)pd.st << kSelfPosBits | (cap != 0 ? wpos0 + pd.x : 0ull);
         } else {
           off[q] = wpos0 + pd.x;
           if (q == q_end - 1) off[q_end] = wpos0 + pd.x + pd.st;
@@ -1902,7 +1899,7 @@ __global__ __launch_bounds__(kQThreads) void k_fill_slices(IndexView v, PipeArgs
     const size_t q = a.q_begin + (size_t)(e >> 4) * a.tile_q + (size_t)(e & 15u) * kWave + lane;
     const bool valid = q < a.q_end;
     const Query qy = load_query<F>(v, cs, a.qchrom, a.qlow, a.qhigh, q, valid);
-    const uint64_t pos = !valid ? 0 : a.perm ? a.src_by_id[a.perm[q]] : a.offsets[q];
+    const uint64_t pos = !valid ? 0 : a.perm ? a.src_by_id[a.perm[q]] & kSelfPosMask : a.offsets[q];
     (void)enumerate_hits<Mode::Fill, F>(v, segs, qy, a.hits, pos, a.cap, nullptr);
     if (S) {
       // ascending ids were asked for: the slice's 64 lists are ordered here, where they were just written (asking for
@@ -2123,11 +2120,11 @@ __global__ __launch_bounds__(kQThreads) void k_permute_lists(const uint64_t *__r
   if (we - wb > 0xFFFFFFFFull) {  // (more than 2^32 ids in 64 lists: every lane copies its own)
     if (i < n)
       for (uint64_t k = 0; k < o1 - o0; ++k)
-        if (o0 + k < cap) hits[o0 + k] = tmp[src[i] + k];
+        if (o0 + k < cap) hits[o0 + k] = tmp[(src[i] & kSelfPosMask) + k];
     return;
   }
   s_end[wave][lane] = (uint32_t)(o1 - wb);
-  s_src[wave][lane] = i < n ? src[i] - (o0 - wb) : 0ull;  // source of the list's first element, minus its place in the piece
+  s_src[wave][lane] = i < n ? (src[i] & kSelfPosMask) - (o0 - wb) : 0ull;  // source of the list's first element, minus its place in the piece
   wave_sync_lds();
   const uint32_t total = (uint32_t)(we - wb);
   // every lane one output element of four consecutive rows of 64 per trip: four bisections, then four gathers in flight,
@@ -2189,7 +2186,7 @@ __global__ __launch_bounds__(kQThreads) void k_permute_lines(const uint64_t *__r
   const uint64_t o0 = offsets[i < n ? i : n], o1 = offsets[i < n ? i + 1 : n];
   const uint64_t wb = __shfl((unsigned long long)o0, 0, kWave);  // the wavefront's piece of the output: [wb, we)
   const uint64_t we = __shfl((unsigned long long)o1, kWave - 1, kWave);
-  const uint64_t sp = i < n && o1 > o0 ? src[i] : 0ull;
+  const uint64_t sp = i < n && o1 > o0 ? src[i] & kSelfPosMask : 0ull;
   if (we - wb > 0xFFFFFFFFull || __any(o1 - o0 > kPermListMax)) {
     // (rare: the element-wise gather of k_permute_lists, one list per lane)
     if (i < n)
@@ -2283,7 +2280,7 @@ __global__ __launch_bounds__(kQThreads) void k_permute_lines(const uint64_t *__r
 }
 
 int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
-                         const uint32_t *d_perm, size_t n, uint32_t *d_counts, uint64_t *d_src_by_id,
+                         const uint32_t *d_perm, size_t n, uint64_t *d_src_by_id,
                          uint64_t *d_offsets_scratch, uint32_t *d_tmp_hits, uint64_t cap, uint64_t *ws, bool self_clean,
                          hipStream_t s) {
   const int flags = (self_clean ? kFlagSelfClean : 0) | kFlagFinal | kFlagSorted;
@@ -2301,7 +2298,7 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
   }
   const unsigned tiles = (unsigned)((n + kPTile - 1) / kPTile);
   PipeArgs a{d_qchrom, d_qlow, d_qhigh, 0, n, d_offsets_scratch, d_tmp_hits, cap, ws, tiles, flags, 1u,
-             nullptr, nullptr, d_perm, d_src_by_id, d_counts, 0u, kPTile};
+             nullptr, nullptr, d_perm, d_src_by_id, nullptr, 0u, kPTile};
   hipLaunchKernelGGL(k_query_pipe_dense, dim3(tiles < wgs ? tiles : wgs), dim3(kPThreads), 0, s, v, a);
   if (cap != 0) {
     a.seq = 0;  // (k_fill_slices: index order)

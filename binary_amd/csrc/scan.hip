@@ -45,6 +45,35 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *lds, T &total) {
   return wave_base + incl - v;
 }
 
+// HI: the values are the bits from `HI` upwards of 64-bit words (HI >= 32: bivx_self_overlaps_dev keeps a list's length above
+// its 38-bit position in ONE word per id, so that the slot-order pass makes one scattered store per interval, not two)
+template <int HI>
+__device__ __forceinline__ uint32_t hi_of(uint32_t high_word) { return high_word >> (HI - 32); }
+
+template <typename OutT, int HI>
+__global__ __launch_bounds__(kScanThreads) void k_tile_reduce_hi(const uint64_t *__restrict__ in, size_t n, OutT *__restrict__ sums) {
+  __shared__ OutT lds[kScanThreads / kWave];
+  const size_t base = (size_t)blockIdx.x * kScanTile;
+  OutT acc = 0;
+  if (base + kScanTile <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
+    uint4 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = p[k * kScanThreads + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += (OutT)hi_of<HI>(a[k].y) + hi_of<HI>(a[k].w);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      size_t i = base + (size_t)k * kScanThreads + threadIdx.x;
+      if (i < n) acc += hi_of<HI>((uint32_t)(in[i] >> 32));
+    }
+  }
+  OutT total;
+  (void)block_exclusive_scan<OutT>(acc, lds, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
 template <typename OutT>
 __global__ __launch_bounds__(kScanThreads) void k_tile_reduce(const uint32_t *__restrict__ in, size_t n,
                                                               OutT *__restrict__ sums) {
@@ -84,21 +113,41 @@ __global__ __launch_bounds__(1024) void k_sums_scan(OutT *__restrict__ sums, siz
   if (threadIdx.x == 0) sums[nb] = carry;
 }
 
-template <typename OutT>
-__global__ __launch_bounds__(kScanThreads) void k_tile_scan(const uint32_t *__restrict__ in, size_t n,
+// HI == 0: `in_v` is an array of 32-bit values; otherwise of 64-bit words whose bits from HI upwards are the values
+template <typename OutT, int HI = 0>
+__global__ __launch_bounds__(kScanThreads) void k_tile_scan(const void *__restrict__ in_v, size_t n,
                                                             const OutT *__restrict__ sums, size_t nb,
                                                             OutT *__restrict__ out) {
   __shared__ OutT lds[kScanThreads / kWave];
   const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;  // blocked
   uint32_t v[kScanItems];
-  if (base + kScanItems <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
-    const uint4 a = *reinterpret_cast<const uint4 *>(in + base);
-    const uint4 b = *reinterpret_cast<const uint4 *>(in + base + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
+  if (HI == 0) {
+    const uint32_t *in = static_cast<const uint32_t *>(in_v);
+    if (base + kScanItems <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(in + base);
+      const uint4 b = *reinterpret_cast<const uint4 *>(in + base + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+      v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
+      for (int k = 0; k < kScanItems; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
+    }
+  } else {
+    const uint64_t *in = static_cast<const uint64_t *>(in_v);
+    if (base + kScanItems <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
+      uint4 a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = p[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] = hi_of<HI ? HI : 32>(a[k].y);
+        v[2 * k + 1] = hi_of<HI ? HI : 32>(a[k].w);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kScanItems; ++k) v[k] = (base + k < n) ? hi_of<HI ? HI : 32>((uint32_t)(in[base + k] >> 32)) : 0u;
+    }
   }
   OutT tsum = 0;
 #pragma unroll
@@ -137,7 +186,22 @@ int exclusive_scan_impl(const uint32_t *d_in, OutT *d_out, size_t n, void *d_scr
   const size_t nb = (n + kScanTile - 1) / kScanTile;
   hipLaunchKernelGGL(k_tile_reduce<OutT>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, d_in, n, sums);
   hipLaunchKernelGGL(k_sums_scan<OutT>, dim3(1), dim3(1024), 0, s, sums, nb);
-  hipLaunchKernelGGL(k_tile_scan<OutT>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, d_in, n, sums, nb, d_out);
+  hipLaunchKernelGGL((k_tile_scan<OutT, 0>), dim3((unsigned)nb), dim3(kScanThreads), 0, s, (const void *)d_in, n, sums, nb, d_out);
+  BIVX_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int HI>
+int exclusive_scan_hi_impl(const uint64_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s) {
+  uint64_t *sums = static_cast<uint64_t *>(d_scratch);
+  if (n == 0) {
+    BIVX_HIP(hipMemsetAsync(d_out, 0, sizeof(uint64_t), s));
+    return 0;
+  }
+  const size_t nb = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL((k_tile_reduce_hi<uint64_t, HI>), dim3((unsigned)nb), dim3(kScanThreads), 0, s, d_in, n, sums);
+  hipLaunchKernelGGL(k_sums_scan<uint64_t>, dim3(1), dim3(1024), 0, s, sums, nb);
+  hipLaunchKernelGGL((k_tile_scan<uint64_t, HI>), dim3((unsigned)nb), dim3(kScanThreads), 0, s, (const void *)d_in, n, sums, nb, d_out);
   BIVX_HIP(hipGetLastError());
   return 0;
 }
@@ -151,6 +215,11 @@ size_t scan_scratch_bytes(size_t n) {
 
 int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s) {
   return exclusive_scan_impl<uint64_t>(d_in, d_out, n, d_scratch, s);
+}
+
+// d_out[i] = sum over j < i of (d_in[j] >> kSelfPosBits): the lengths kept above the positions (common.h)
+int exclusive_scan_lengths_u64(const uint64_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s) {
+  return exclusive_scan_hi_impl<kSelfPosBits>(d_in, d_out, n, d_scratch, s);
 }
 
 }  // namespace bivx
