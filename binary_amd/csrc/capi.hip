@@ -1536,10 +1536,11 @@ int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_of
   // a scan of the lengths, then the lists are gathered into id order
   BIVX_TRY(launch_self_overlaps(view, q, q + n, q + 2 * n, idx->d_id, n, d_src, d_offsets, hit_capacity ? d_tmp : nullptr,
                                 hit_capacity, static_cast<uint64_t *>(ws), true, s));
-  BIVX_TRY(exclusive_scan_lengths_u64(d_src, d_offsets, n, scan_scr, s));
-  if (hit_capacity) {
-    bool sorted = false;  // (the line-wise gather orders the lists while they pass through LDS)
-    BIVX_TRY(launch_permute_lists(d_offsets, d_src, d_tmp, d_hit_ids, n, hit_capacity, sort_by_id != 0, &sorted, s));
+  if (!hit_capacity) {
+    BIVX_TRY(exclusive_scan_lengths_u64(d_src, d_offsets, n, scan_scr, s));
+  } else {
+    bool sorted = false;  // (the line-wise gather makes the offsets itself, and orders the lists while they pass through LDS)
+    BIVX_TRY(launch_permute_lists(d_offsets, d_src, d_tmp, d_hit_ids, n, hit_capacity, sort_by_id != 0, &sorted, scan_scr, s));
     if (sort_by_id && !sorted) BIVX_TRY(launch_sort_hits(d_offsets, d_hit_ids, n, hit_capacity, s));
   }
   return 0;

@@ -128,6 +128,11 @@ int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void
 constexpr int kSelfPosBits = 38;
 constexpr uint64_t kSelfPosMask = (1ull << kSelfPosBits) - 1ull;
 int exclusive_scan_lengths_u64(const uint64_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s);
+// the same lengths summed per block of 256 ids (block_sums) and, per tile of 8 192 ids, the exclusive prefix of the tile sums
+// (tile_prefix; the grand total behind the last tile), both inside d_scratch (scan_scratch_bytes): what k_permute_lines needs to
+// make the offsets itself
+int self_length_sums(const uint64_t *d_in, size_t n, void *d_scratch, const uint64_t **tile_prefix, const uint64_t **block_sums,
+                     hipStream_t s);
 
 // ---- build.hip --------------------------------------------------------------------------------------
 // the partition of interval i is chrom[i] * ntypes + type[i] (type == nullptr: chrom[i])
@@ -219,8 +224,9 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
                          const uint32_t *d_perm, size_t n, uint64_t *d_src_by_id,
                          uint64_t *d_offsets_scratch, uint32_t *d_tmp_hits, uint64_t cap, uint64_t *ws, bool self_clean,
                          hipStream_t s);
-int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
-                         uint64_t cap, bool sort_ids, bool *sorted, hipStream_t s);
+// also leaves d_offsets (n + 1): the exclusive prefix sum of the lists' lengths (d_scan: scan_scratch_bytes(n))
+int launch_permute_lists(uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
+                         uint64_t cap, bool sort_ids, bool *sorted, void *d_scan, hipStream_t s);
 int launch_query_pipe(const IndexView &v, const uint32_t *d_qchrom, const uint32_t *d_qlow, const uint32_t *d_qhigh,
                       size_t q0, size_t q1, uint64_t *d_offsets, uint32_t *d_hits, uint64_t cap, uint64_t *ws,
                       int flags, uint32_t sort_seq, uint32_t *d_counts, uint64_t *d_total, hipStream_t s);

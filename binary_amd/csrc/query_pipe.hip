@@ -2175,18 +2175,54 @@ constexpr uint32_t kPermBuf = BIVX_PERM_BUF;      // ids a wavefront puts togeth
 constexpr uint32_t kPermListMax = 1024;  // a wavefront with a longer list takes the element-wise way
 
 // S: every list leaves in ascending order (ordered by its lane while the piece sits in LDS: no second pass over the ids)
+// The kernel makes the offsets itself — the exclusive prefix sum of the lists' lengths (the words' high bits) — and writes them:
+// a workgroup's 256 ids begin where its tile of 8 192 begins (tile_prefix) + the blocks of 256 before it inside the tile
+// (block_sums; self_length_sums) + the wavefronts before this one. (A scan pass in front read the words and wrote the offsets,
+// and this kernel read both again: 0.19 ms of 4.2 at config 5.)
 template <bool S>
-__global__ __launch_bounds__(kQThreads) void k_permute_lines(const uint64_t *__restrict__ offsets,
+__global__ __launch_bounds__(kQThreads) void k_permute_lines(uint64_t *__restrict__ offsets,
                                                              const uint64_t *__restrict__ src, const uint32_t *__restrict__ tmp,
-                                                             uint32_t *__restrict__ hits, size_t n, uint64_t cap) {
+                                                             uint32_t *__restrict__ hits, size_t n, uint64_t cap,
+                                                             const uint64_t *__restrict__ tile_prefix,
+                                                             const uint64_t *__restrict__ block_sums) {
+  static_assert(kQThreads == 256, "self_length_sums sums blocks of 256 ids");
   __shared__ __attribute__((aligned(16))) uint32_t s_buf[kQWaves][kPermBuf];
   __shared__ uint4 s_tab[kQWaves][kWave];  // per list: (source low, source high, length, place in the run)
+  __shared__ uint64_t s_wtot[kQWaves];
+  __shared__ uint64_t s_base;
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const size_t i = (size_t)blockIdx.x * kQThreads + threadIdx.x;
-  const uint64_t o0 = offsets[i < n ? i : n], o1 = offsets[i < n ? i + 1 : n];
+  const uint64_t word = i < n ? src[i] : 0ull;
+  uint64_t o0, o1;
+  {
+    const uint64_t mylen = word >> kSelfPosBits;
+    unsigned long long incl = mylen;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const unsigned long long o = __shfl_up(incl, d, kWave);
+      if ((int)lane >= d) incl += o;
+    }
+    if (lane == kWave - 1) s_wtot[wave] = incl;
+    if (wave == 0) {  // where the workgroup's ids begin
+      const uint32_t b = blockIdx.x, first = b & ~31u;
+      unsigned long long part = lane < (b & 31u) ? block_sums[first + lane] : 0ull;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) part += __shfl_xor(part, d, kWave);
+      if (lane == 0) s_base = tile_prefix[b >> 5] + part;
+    }
+    __syncthreads();
+    uint64_t before = s_base;
+    for (uint32_t w = 0; w < wave; ++w) before += s_wtot[w];
+    o1 = before + incl;
+    o0 = o1 - mylen;
+    if (i < n) {
+      offsets[i] = o0;
+      if (i == n - 1) offsets[n] = o1;
+    }
+  }
   const uint64_t wb = __shfl((unsigned long long)o0, 0, kWave);  // the wavefront's piece of the output: [wb, we)
   const uint64_t we = __shfl((unsigned long long)o1, kWave - 1, kWave);
-  const uint64_t sp = i < n && o1 > o0 ? src[i] & kSelfPosMask : 0ull;
+  const uint64_t sp = i < n && o1 > o0 ? word & kSelfPosMask : 0ull;
   if (we - wb > 0xFFFFFFFFull || __any(o1 - o0 > kPermListMax)) {
     // (rare: the element-wise gather of k_permute_lists, one list per lane)
     if (i < n)
@@ -2309,24 +2345,30 @@ int launch_self_overlaps(const IndexView &v, const uint32_t *d_qchrom, const uin
 }
 
 // *sorted: the lists left in ascending order (sort_ids asked for it and the line-wise kernel ran), else the caller orders them
-int launch_permute_lists(const uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
-                         uint64_t cap, bool sort_ids, bool *sorted, hipStream_t s) {
+int launch_permute_lists(uint64_t *d_offsets, const uint64_t *d_src, const uint32_t *d_tmp, uint32_t *d_hits, size_t n,
+                         uint64_t cap, bool sort_ids, bool *sorted, void *d_scan, hipStream_t s) {
   *sorted = false;
-  if (n == 0) return 0;
   static const bool by_elements = [] {  // (BIVX_PERMUTE=elements: the first form, for comparison)
     const char *e = std::getenv("BIVX_PERMUTE");
     return e && e[0] == 'e';
   }();
-  if (by_elements)
+  if (n == 0 || by_elements) {
+    BIVX_TRY(exclusive_scan_lengths_u64(d_src, d_offsets, n, d_scan, s));
+    if (n == 0) return 0;
     hipLaunchKernelGGL(k_permute_lists, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s, d_offsets,
                        d_src, d_tmp, d_hits, n, cap);
-  else if (sort_ids) {
+    BIVX_HIP(hipGetLastError());
+    return 0;
+  }
+  const uint64_t *tile_prefix = nullptr, *block_sums = nullptr;
+  BIVX_TRY(self_length_sums(d_src, n, d_scan, &tile_prefix, &block_sums, s));
+  if (sort_ids) {
     hipLaunchKernelGGL(k_permute_lines<true>, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s,
-                       d_offsets, d_src, d_tmp, d_hits, n, cap);
+                       d_offsets, d_src, d_tmp, d_hits, n, cap, tile_prefix, block_sums);
     *sorted = true;
   } else {
     hipLaunchKernelGGL(k_permute_lines<false>, dim3((unsigned)((n + kQThreads - 1) / kQThreads)), dim3(kQThreads), 0, s,
-                       d_offsets, d_src, d_tmp, d_hits, n, cap);
+                       d_offsets, d_src, d_tmp, d_hits, n, cap, tile_prefix, block_sums);
   }
   BIVX_HIP(hipGetLastError());
   return 0;

@@ -191,6 +191,48 @@ int exclusive_scan_impl(const uint32_t *d_in, OutT *d_out, size_t n, void *d_scr
   return 0;
 }
 
+// Sums of the values per block of 256 and per tile of 8 192 (= 32 blocks) in ONE read of the words: what a kernel that takes 256
+// consecutive values per workgroup needs to know where its piece of their prefix sum begins — the tile's exclusive prefix (after
+// k_sums_scan) + the blocks before it inside the tile — so that it can make the prefix sum itself instead of reading it
+// (bivx_self_overlaps_dev: k_permute_lines writes the offsets it computes; a separate scan pass read the words and wrote the
+// offsets, and the gather read both again).
+template <int HI>
+__global__ __launch_bounds__(kScanThreads) void k_block_sums_hi(const uint64_t *__restrict__ in, size_t n,
+                                                                uint64_t *__restrict__ sums256, uint64_t *__restrict__ sums8192) {
+  static_assert(kScanThreads == 1024 && kScanItems == 8, "32 threads x 8 values = a block of 256");
+  __shared__ uint64_t lds[kScanThreads / kWave];
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;  // blocked: 32 threads = 256 values
+  uint32_t mine = 0;  // (eight values below 2^26 each)
+  if (base + kScanItems <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
+    uint4 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mine += hi_of<HI>(a[k].y) + hi_of<HI>(a[k].w);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+      if (base + k < n) mine += hi_of<HI>((uint32_t)(in[base + k] >> 32));
+  }
+  unsigned long long sum = mine;
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) sum += __shfl_xor(sum, d, kWave);  // (the two halves of a wavefront are two blocks)
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  if ((lane & 31) == 0) {
+    const size_t b = (size_t)blockIdx.x * (kScanTile / 256) + (threadIdx.x >> 5);
+    if (b * 256 < n) sums256[b] = sum;
+  }
+  const unsigned long long both = sum + __shfl_xor(sum, 32, kWave);
+  if (lane == 0) lds[wave] = both;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kScanThreads / kWave; ++w) t += lds[w];
+    sums8192[blockIdx.x] = t;
+  }
+}
+
 template <int HI>
 int exclusive_scan_hi_impl(const uint64_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s) {
   uint64_t *sums = static_cast<uint64_t *>(d_scratch);
@@ -208,9 +250,24 @@ int exclusive_scan_hi_impl(const uint64_t *d_in, uint64_t *d_out, size_t n, void
 
 }  // namespace
 
-size_t scan_scratch_bytes(size_t n) {
+size_t scan_scratch_bytes(size_t n) {  // [tile sums: nb + 2 | block sums: 32 per tile]
   const size_t nb = (n + kScanTile - 1) / kScanTile;
-  return (nb + 2) * sizeof(uint64_t);
+  return (nb + 2 + nb * (kScanTile / 256)) * sizeof(uint64_t);
+}
+
+// sums of the lengths (the words' bits from kSelfPosBits up) per block of 256 words, and the exclusive prefix of the sums per tile
+// of 8 192 (the grand total behind the last): *tile_prefix = d_scratch, *block_sums behind it
+int self_length_sums(const uint64_t *d_in, size_t n, void *d_scratch, const uint64_t **tile_prefix, const uint64_t **block_sums,
+                     hipStream_t s) {
+  const size_t nb = (n + kScanTile - 1) / kScanTile;
+  uint64_t *t = static_cast<uint64_t *>(d_scratch), *b = t + nb + 2;
+  *tile_prefix = t;
+  *block_sums = b;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((k_block_sums_hi<kSelfPosBits>), dim3((unsigned)nb), dim3(kScanThreads), 0, s, d_in, n, b, t);
+  hipLaunchKernelGGL(k_sums_scan<uint64_t>, dim3(1), dim3(1024), 0, s, t, nb);
+  BIVX_HIP(hipGetLastError());
+  return 0;
 }
 
 int exclusive_scan_u32_u64(const uint32_t *d_in, uint64_t *d_out, size_t n, void *d_scratch, hipStream_t s) {
