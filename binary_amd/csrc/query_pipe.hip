@@ -1991,6 +1991,8 @@ bool pipe_ms_eligible(const IndexView &v, size_t q, uint64_t cap, bool unordered
 }
 
 size_t pipe_queries_per_launch() { return (size_t)kFMaxTiles * kPTile; }
+static_assert((uint64_t)kFMaxTiles * kPTile < (1ull << (64 - kSelfPosBits)),
+              "bivx_self_overlaps_dev keeps a list's length (at most the launch's intervals) above kSelfPosBits of one word");
 size_t pipe_ms_queries_per_launch() { return (size_t)kFMaxTiles * kMsTile; }
 
 // Compute units of the calling thread's current device, looked up once per device and process (a launch used to ask the
