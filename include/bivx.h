@@ -305,7 +305,7 @@ int bivx_query_dev_u(const bivx_index *idx, const uint32_t *d_qchrom, const uint
  * in the index's OWN order, where neighbouring queries read neighbouring records (every line of the index is fetched
  * once per wavefront instead of once per query), and then gathers the lists into id order; no query arrays are read.
  * Same offsets and the same ids as the general call, list by list in the same order. It keeps a per-stream scratch of
- * 12 n + 4 hit_capacity bytes. d_offsets[n] is the true total even when it exceeds hit_capacity — the contents of
+ * 8 n + 4 hit_capacity bytes (n below 2^26, hit_capacity below 2^38). d_offsets[n] is the true total even when it exceeds hit_capacity — the contents of
  * d_hit_ids are then unspecified and the call is repeated with a buffer of at least the total (hit_capacity 0 gives
  * the offsets only). Indexes the fast path does not cover (several length classes per chromosome, positional
  * hotspots, fewer than 61 440 intervals) take the general call, with its semantics. */
