@@ -305,10 +305,11 @@ int bivx_query_dev_u(const bivx_index *idx, const uint32_t *d_qchrom, const uint
  * in the index's OWN order, where neighbouring queries read neighbouring records (every line of the index is fetched
  * once per wavefront instead of once per query), and then gathers the lists into id order; no query arrays are read.
  * Same offsets and the same ids as the general call, list by list in the same order. It keeps a per-stream scratch of
- * 8 n + 4 hit_capacity bytes (n below 2^26, hit_capacity below 2^38). d_offsets[n] is the true total even when it exceeds hit_capacity — the contents of
- * d_hit_ids are then unspecified and the call is repeated with a buffer of at least the total (hit_capacity 0 gives
- * the offsets only). Indexes the fast path does not cover (several length classes per chromosome, positional
- * hotspots, fewer than 61 440 intervals) take the general call, with its semantics. */
+ * 8 n + 4 hit_capacity bytes (hit_capacity below 2^38, else BIVX_E_RANGE). d_offsets[n] is the true total even when it
+ * exceeds hit_capacity — the contents of d_hit_ids are then unspecified and the call is repeated with a buffer of at
+ * least the total (hit_capacity 0 gives the offsets only). Indexes the fast path does not cover (several length classes
+ * per chromosome, positional hotspots, fewer than 61 440 or more than 62.9 M intervals) take the general call, with its
+ * semantics. */
 int bivx_self_overlaps_dev(const bivx_index *idx, int sort_by_id, uint64_t *d_offsets, uint32_t *d_hit_ids,
                            uint64_t hit_capacity, void *stream);
 
