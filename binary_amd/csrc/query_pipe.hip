@@ -1175,7 +1175,10 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
       if (q < q_end) {
         if (perm) {  // (bivx_self_overlaps_dev: count and list position go where the query's id says)
           // (ONE scattered 8-byte store per interval: the list's length above the position where it begins)
-          p->a.src_by_id[perm[q]] = (uint64_t)cnt << kSelfPosBits | (cap != 0 ? wpos0 + loff : 0ull);
+          // (a position beyond the buffer — the true total may be far beyond 2^38 — is never read: it is stored as all ones so
+          // that it cannot run into the length, which the offsets are made of)
+          const uint64_t pos = cap != 0 ? wpos0 + loff : 0ull;
+          p->a.src_by_id[perm[q]] = (uint64_t)cnt << kSelfPosBits | (pos < kSelfPosMask ? pos : kSelfPosMask);
         } else {
           stream_store(off + q, wpos0 + loff);
           if (q == q_end - 1) off[q_end] = wpos0 + loff + cnt;
@@ -1222,7 +1225,8 @@ __global__ __launch_bounds__(kPThreads, 8) void k_query_pipe_dense(IndexView v_i
     } else {
       if (q < q_end) {
         if (perm) {
-          p->a.src_by_id[perm[q]] = (uint64_t)pd.st << kSelfPosBits | (cap != 0 ? wpos0 + pd.x : 0ull);
+          const uint64_t pos = cap != 0 ? wpos0 + pd.x : 0ull;
+          p->a.src_by_id[perm[q]] = (uint64_t)pd.st << kSelfPosBits | (pos < kSelfPosMask ? pos : kSelfPosMask);
         } else {
           off[q] = wpos0 + pd.x;
           if (q == q_end - 1) off[q_end] = wpos0 + pd.x + pd.st;

@@ -137,3 +137,33 @@ def test_self_overlaps_after_rebuild_and_on_two_streams():
         torch.cuda.synchronize()
         for s_off, s_hits in res:
             assert torch.equal(s_off, g_off) and torch.equal(s_hits[:H], g_hits[:H])
+
+
+def test_a_total_beyond_2_to_the_38_leaves_the_offsets_exact():
+    """The slot-order pass keeps a list's length above its 38-bit position in one word (query_pipe.hip, kSelfPosBits). With
+    640 000 intervals that nearly all overlap each other the call has 3.6e11 pairs — more than 2^38 — and a caller that
+    offers a small buffer must still get every offset, and the true total in offsets[n], to come back with a larger one
+    (bivx.h): a position beyond the buffer may not run into the length bits. Counts against sort + searchsorted
+    (interval_tree.hpp:119-121)."""
+    import torch
+    from binary_amd import IntervalIndex
+    rng = np.random.default_rng(38)
+    n = 640_000
+    low = rng.permutation(np.arange(n, dtype=np.uint64) * 1500 + 7).astype(np.uint32)   # distinct, spread lows: no crowded cell
+    high = (low.astype(np.uint64) + 960_000_000 + rng.integers(0, 1000, n)).astype(np.uint32)
+    cnt = np.searchsorted(np.sort(low), high, "right") - np.searchsorted(np.sort(high), low, "left")
+    total = int(cnt.sum())
+    assert total > (1 << 38)
+    with IntervalIndex(0) as idx:
+        idx.insert_node(low, high)
+        idx.build()
+        assert idx.stats()["n_segments"] == 1
+        off = torch.full((n + 1,), -1, dtype=torch.int64, device="cuda:0")
+        hits = torch.full((4096,), -1, dtype=torch.int32, device="cuda:0")
+        idx.self_overlaps_device(off, hits)
+        idx.stream_status()
+        off = off.cpu().numpy()
+    assert int(off[-1]) == total
+    assert np.array_equal(np.diff(off), cnt)
+    first = np.flatnonzero((low <= high[0]) & (high >= low[0]))[:4096 if cnt[0] >= 4096 else int(cnt[0])]
+    assert np.array_equal(np.sort(hits.cpu().numpy().view(np.uint32)[: first.size]), np.sort(first)) or cnt[0] > 4096
