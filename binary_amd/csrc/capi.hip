@@ -321,24 +321,19 @@ void note_reader(const bivx_index *idx, hipStream_t s) {
 }
 
 // Before the built arrays (or the append-order columns they were made from) are overwritten: every query, fill or
-// self-overlap call enqueued so far on a caller stream must have finished reading them. The streams are waited for one
-// by one (an idle stream costs a microsecond); a stream the caller has destroyed since has finished its work — its
-// stale handle is reported as invalid by the runtime and skipped.
+// self-overlap call enqueued so far on a caller stream must have finished reading them. The streams themselves are NOT touched
+// again: a caller may have destroyed one since, and the runtime does not report such a handle as invalid — it dereferences it
+// (a crash in hipStreamSynchronize, found with a parked index object whose last owner's streams were gone). If any caller
+// stream has read the index since the last wait, the whole device is waited for; the usual build — no device-pointer call
+// since the last one — skips this.
 int wait_for_readers(bivx_index *idx) {
-  std::vector<hipStream_t> streams;
+  bool any;
   {
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
-    streams.assign(idx->reader_streams.begin(), idx->reader_streams.end());
+    any = !idx->reader_streams.empty();
     idx->reader_streams.clear();
   }
-  for (hipStream_t rs : streams) {
-    const hipError_t e = hipStreamSynchronize(rs);
-    if (e == hipSuccess) continue;
-    (void)hipGetLastError();
-    if (e == hipErrorInvalidHandle || e == hipErrorInvalidResourceHandle || e == hipErrorContextIsDestroyed) continue;
-    set_error("waiting for a caller stream that reads the index failed: %s", hipGetErrorString(e));
-    return BIVX_E_HIP;
-  }
+  if (any) BIVX_HIP(hipDeviceSynchronize());
   return 0;
 }
 
@@ -853,6 +848,10 @@ bool park(bivx_index *idx) {
   }
   for (hipEvent_t ev : idx->ev_pending) idx->ev_free.push_back(ev);
   idx->ev_pending.clear();
+  {  // (the device was just waited for: the last owner's caller streams are done with the index, and may be gone)
+    std::lock_guard<std::mutex> lock(idx->ws_mutex);
+    idx->reader_streams.clear();
+  }
   if (idx->typed && idx->d_type && idx->n) {
     if (hipMemsetAsync(idx->d_type, 0, idx->n, idx->stream) != hipSuccess || hipStreamSynchronize(idx->stream) != hipSuccess)
       return false;

@@ -577,3 +577,50 @@ def test_typed_append_after_untyped_ones_drops_the_appends_statistics(monkeypatc
         _check_csr(off, hits, _brute(chrom, low, high, np.ones(n, bool), qc, qlo, qhi), True)
         off, hits = idx.find_overlaps(qlo, qhi, qc, svtype=2)
         _check_csr(off, hits, _brute(chrom, low, high, typ == 2, qc, qlo, qhi), True)
+
+
+def test_rebuild_after_a_caller_stream_that_read_the_index_is_gone():
+    """A device-pointer call reads the index on the caller's stream; a rebuild (or bivx_clear, or the next owner of a parked
+    index object) must come after it — but may not touch that stream again: the caller is free to destroy it, and the runtime
+    dereferences a stale handle instead of reporting it (a crash in hipStreamSynchronize inside bivx_build, found when a
+    parked object's next owner waited for its predecessor's streams). capi.hip wait_for_readers."""
+    import ctypes as C
+    import torch
+    from binary_amd import IntervalIndex
+    hip = C.CDLL("libamdhip64.so")
+    rng = np.random.default_rng(4)
+    n, q = 200_000, 100_000
+    low = rng.integers(0, 50_000_000, n).astype(np.uint32)
+    high = (low + rng.integers(0, 800, n)).astype(np.uint32)
+    qlo = rng.integers(0, 50_000_000, q).astype(np.uint32)
+    qhi = (qlo + rng.integers(0, 800, q)).astype(np.uint32)
+    to = lambda a: torch.from_numpy(a.view(np.int32).copy()).cuda()
+    exp = _brute(np.zeros(n, np.uint32), low, high, np.ones(n, bool), np.zeros(50, np.uint32), qlo[:50], qhi[:50])
+    for parked in (False, True):
+        idx = IntervalIndex(0)
+        idx.insert_node(low, high)
+        idx.build()
+        for _ in range(6):            # several short-lived streams: their handles are stale by the time of the rebuild
+            raw = C.c_void_p()
+            assert hip.hipStreamCreateWithFlags(C.byref(raw), 1) == 0
+            ext = torch.cuda.ExternalStream(raw.value)
+            with torch.cuda.stream(ext):
+                dq, dqh = to(qlo), to(qhi)
+                off, hits = idx.find_overlaps_device(dq, dqh, sort_by_id=True)
+            ext.synchronize()
+            assert hip.hipStreamDestroy(raw) == 0
+            junk = [C.create_string_buffer(4096) for _ in range(64)]   # the freed handles' memory is reused
+            del junk
+        if parked:
+            idx.close()               # parked; the next create on this device gets the object back
+            idx = IntervalIndex(0)
+            idx.insert_node(low, high)
+        else:
+            idx.insert_node(low[:10], high[:10])
+        idx.build()
+        off, hits = idx.find_overlaps(qlo[:50], qhi[:50])
+        got = [np.asarray(hits[int(off[k]):int(off[k + 1])]) for k in range(50)]
+        for k in range(50):
+            e = exp[k] if parked else np.concatenate([exp[k], n + np.flatnonzero((low[:10] <= qhi[k]) & (high[:10] >= qlo[k]))])
+            assert np.array_equal(got[k].astype(np.int64), e), k
+        idx.close()
