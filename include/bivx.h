@@ -20,8 +20,9 @@
  *   - calls taking `const bivx_index*` are thread-safe against each other; mutating calls are not. Host-pointer query
  *     calls made from several threads on one index run side by side (each on a stream, an error block and a workspace of
  *     its own: the reference shares one tree across its pool threads, mapper.cpp:127-142)
- *   - bivx_build and bivx_clear wait for device-pointer calls that still read the index on caller streams; the caller
- *     does not have to synchronise before it rebuilds
+ *   - bivx_build and bivx_clear wait for device-pointer calls that still read the index on caller streams (for the whole
+ *     device, if there was such a call since the last build); the caller does not have to synchronise before it rebuilds,
+ *     and may destroy its streams whenever their work is done
  *   - `_dev` entry points take DEVICE pointers and a hipStream_t (as void*; NULL = default stream) and
  *     never synchronise; the others take HOST pointers and return when the result is in host memory
  *   - there is no CPU fallback: without a usable gfx950 device bivx_create fails with BIVX_E_HIP
