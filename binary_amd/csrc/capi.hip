@@ -387,6 +387,7 @@ int ensure_capacity(bivx_index *idx, size_t need) {
   return 0;
 }
 
+constexpr size_t kMaxIdleWorkspaces = 32;  // per-stream workspaces an index keeps across a rebuild
 constexpr size_t kAppendStatsFrom = (size_t)4 << 20;  // intervals in an index's first append from which statistics ride on appends
 
 int append_impl(bivx_index *idx, const uint32_t *chrom, const uint32_t *low, const uint32_t *high,
@@ -1059,6 +1060,15 @@ int bivx_build(bivx_index *idx) {
     std::lock_guard<std::mutex> lock(idx->ws_mutex);
     // on the build stream, which is synchronised before bivx_build returns (a plain hipMemset runs on the null
     // stream, which non-blocking streams do not wait for)
+    // (a workspace per caller stream ever seen, 4.7 MB each: a caller that makes a stream per request would pile them up.
+    // Nothing is running on them here — the readers were just waited for — so a large pile is simply dropped.)
+    if (idx->ws_of_stream.size() > kMaxIdleWorkspaces) {
+      for (auto &kv : idx->ws_of_stream) {
+        (void)hipFree(kv.second.p);
+        (void)hipFree(kv.second.self_p);
+      }
+      idx->ws_of_stream.clear();
+    }
     for (auto &kv : idx->ws_of_stream) BIVX_HIP(hipMemsetAsync(kv.second.p, 0, fused_workspace_bytes(0), s));
   }
   free_built(idx);
