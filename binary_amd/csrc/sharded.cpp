@@ -652,6 +652,7 @@ static int query_dev_impl(const ShardedState *st, const uint32_t *qchrom, const 
     }
     BIVX_NCCL(ncclGroupStart());
     for (size_t s = 0; s < k; ++s) {
+      OnDevice g(st->devices[s]);  // (a communicator's calls are made with its device current)
       uint64_t *sz = static_cast<uint64_t *>(st->dev[s].sizes.p);
       const ncclResult_t e = ncclAllGather(sz, sz + 2, 2, ncclUint64, st->comms[s], st->dev[s].stream);
       if (e != ncclSuccess) {
@@ -702,6 +703,7 @@ static int query_dev_impl(const ShardedState *st, const uint32_t *qchrom, const 
     for (size_t s = 1; s < k && e == ncclSuccess; ++s) {
       if (nq[s]) e = ncclRecv(o_off + qdisp[s], nq[s], ncclUint64, (int)s, st->comms[0], rs);
       if (e == ncclSuccess && nh[s]) e = ncclRecv(o_hits + hdisp[s], nh[s], ncclUint32, (int)s, st->comms[0], rs);
+      OnDevice g(st->devices[s]);  // (the peer's sends with the peer's device current; the root's is restored behind them)
       if (e == ncclSuccess && nq[s]) e = ncclSend(st->dev[s].off.p, nq[s], ncclUint64, 0, st->comms[s], st->dev[s].stream);
       if (e == ncclSuccess && nh[s]) e = ncclSend(st->dev[s].hits.p, nh[s], ncclUint32, 0, st->comms[s], st->dev[s].stream);
     }
